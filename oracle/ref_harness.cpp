@@ -1,0 +1,255 @@
+// TEST INFRASTRUCTURE -- not product code.
+//
+// Driver for the *real* reference (Han9527/CAFExp), compiled in place from
+// /root/reference/src/*.cpp by oracle/Makefile into oracle/_ref/ (git-ignored).
+// This file is our own code: it only calls the reference's public API
+// (src/probability.h, src/matrix_cache.h, src/core.h, src/base_model.h,
+// src/gamma_core.h ...) the way the reference's own cafexp.cpp / test.cpp do.
+// No reference source is copied into the repo.
+//
+// Usage: ref_harness <job> [key=value ...]   -> one JSON object on stdout.
+// Jobs:
+//   bd        lambda= t= s= c=                   the_probability_of_going_from_parent_fam_size_to_c
+//   bdlog     s= c= log_alpha= coeff=            birthdeath_rate_with_log_alpha
+//   matrix    n= lambda= t=                      matrix_cache::precalculate_matrices + get_matrix (key-quantized)
+//   gamma     k= alpha=                          get_gamma (PAML discrete gamma)
+//   key       lambda= t=                         matrix_cache_key de-quantized values
+//   prune     newick= counts=A:3,B:6 lambda= mult= m= r= [errfile=]   inference_prune root vector
+//   score     tree= families= model=base|gamma [lambda=|lambdas=a,b lambda_tree=] [k= alpha=]
+//             [errfile=] [prior=uniform|poisson:X] [rootdist=file] [rootfilter=1] [limit=N]
+//             [m= r=]  -> -lnL, per-family table, wall seconds
+//   time_matrices n= lambda= count= t0=          wall seconds of precalculate_matrices for `count` branch lengths
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <random>
+#include <sstream>
+#include <string>
+#include <vector>
+#include <omp.h>
+
+#include "src/io.h"
+#include "src/core.h"
+#include "src/user_data.h"
+#include "src/base_model.h"
+#include "src/gamma_core.h"
+#include "src/gamma.h"
+#include "src/matrix_cache.h"
+#include "src/probability.h"
+#include "src/root_equilibrium_distribution.h"
+#include "src/root_distribution.h"
+#include "src/lambda.h"
+#include "src/error_model.h"
+#include "src/gene_family.h"
+
+std::mt19937 randomizer_engine(10);   // main.cpp:3 / test.cpp:35 define this global
+void init_lgamma_cache();             // probability.cpp:66
+
+typedef std::map<std::string, std::string> kv_t;
+
+static kv_t parse_args(int argc, char** argv, int first) {
+    kv_t kv;
+    for (int i = first; i < argc; ++i) {
+        std::string a(argv[i]);
+        size_t eq = a.find('=');
+        if (eq == std::string::npos) { kv[a] = "1"; continue; }
+        kv[a.substr(0, eq)] = a.substr(eq + 1);
+    }
+    return kv;
+}
+static bool has(const kv_t& kv, const char* k) { return kv.find(k) != kv.end(); }
+static std::string gets(const kv_t& kv, const char* k, const char* dflt = "") {
+    auto it = kv.find(k); return it == kv.end() ? std::string(dflt) : it->second;
+}
+static double getd(const kv_t& kv, const char* k, double dflt = 0) {
+    auto it = kv.find(k); return it == kv.end() ? dflt : std::stod(it->second);
+}
+static int geti(const kv_t& kv, const char* k, int dflt = 0) {
+    auto it = kv.find(k); return it == kv.end() ? dflt : std::stoi(it->second);
+}
+static void pd(double v) {
+    if (std::isinf(v)) printf(v > 0 ? "\"inf\"" : "\"-inf\"");
+    else if (std::isnan(v)) printf("\"nan\"");
+    else printf("%.17g", v);
+}
+static void parr(const char* name, const std::vector<double>& v) {
+    printf("\"%s\": [", name);
+    for (size_t i = 0; i < v.size(); ++i) { if (i) printf(", "); pd(v[i]); }
+    printf("]");
+}
+static double now() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static int job_bd(const kv_t& kv) {
+    double v = the_probability_of_going_from_parent_fam_size_to_c(getd(kv, "lambda"), getd(kv, "t"), geti(kv, "s"), geti(kv, "c"));
+    printf("{\"value\": "); pd(v); printf("}\n");
+    return 0;
+}
+static int job_bdlog(const kv_t& kv) {
+    double v = birthdeath_rate_with_log_alpha(geti(kv, "s"), geti(kv, "c"), getd(kv, "log_alpha"), getd(kv, "coeff"));
+    printf("{\"value\": "); pd(v); printf("}\n");
+    return 0;
+}
+static int job_key(const kv_t& kv) {
+    matrix_cache_key key(1, getd(kv, "lambda"), getd(kv, "t"));
+    printf("{\"lambda_q\": "); pd(key.lambda()); printf(", \"t_q\": "); pd(key.branch_length()); printf("}\n");
+    return 0;
+}
+static int job_matrix(const kv_t& kv) {
+    int n = geti(kv, "n");
+    double lambda = getd(kv, "lambda"), t = getd(kv, "t");
+    matrix_cache calc(n);
+    calc.precalculate_matrices({ lambda }, std::set<double>{ t });
+    const matrix* m = calc.get_matrix(t, lambda);
+    std::vector<double> flat((size_t)n * n);
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) flat[(size_t)i * n + j] = m->get(i, j);
+    printf("{\"n\": %d, ", n); parr("values", flat); printf("}\n");
+    return 0;
+}
+static int job_gamma(const kv_t& kv) {
+    int k = geti(kv, "k");
+    std::vector<double> freq(k), rate(k);
+    get_gamma(freq, rate, getd(kv, "alpha"));
+    printf("{"); parr("cat_probs", freq); printf(", "); parr("multipliers", rate); printf("}\n");
+    return 0;
+}
+static error_model* load_error_model(const std::string& path) {
+    std::ifstream f(path);
+    if (!f.is_open()) throw std::runtime_error("cannot open " + path);
+    error_model* em = new error_model;
+    read_error_model_file(f, em);
+    return em;
+}
+static int job_prune(const kv_t& kv) {
+    std::unique_ptr<clade> tree(parse_newick(gets(kv, "newick"), false));
+    gene_family fam;
+    std::stringstream ss(gets(kv, "counts"));
+    std::string tok;
+    while (std::getline(ss, tok, ',')) {
+        size_t c = tok.find(':');
+        fam.set_species_size(tok.substr(0, c), std::stoi(tok.substr(c + 1)));
+    }
+    double lambda = getd(kv, "lambda"), mult = getd(kv, "mult", 1.0);
+    int M = geti(kv, "m"), R = geti(kv, "r");
+    single_lambda lam(lambda);
+    std::unique_ptr<error_model> em;
+    if (has(kv, "errfile")) em.reset(load_error_model(gets(kv, "errfile")));
+    matrix_cache cache(std::max(M, R) + 1);
+    cache.precalculate_matrices({ lambda * mult }, tree->get_branch_lengths());
+    auto v = inference_prune(fam, cache, &lam, em.get(), tree.get(), mult, R, M);
+    printf("{"); parr("root", v); printf("}\n");
+    return 0;
+}
+
+static int job_score(const kv_t& kv) {
+    input_parameters p;
+    p.tree_file_path = gets(kv, "tree");
+    p.input_file_path = gets(kv, "families");
+    if (has(kv, "lambda")) p.fixed_lambda = getd(kv, "lambda");
+    if (has(kv, "lambdas")) { p.fixed_multiple_lambdas = gets(kv, "lambdas"); p.lambda_tree_file_path = gets(kv, "lambda_tree"); }
+    if (has(kv, "errfile")) { p.use_error_model = true; p.error_model_file_path = gets(kv, "errfile"); }
+    if (has(kv, "rootdist")) p.rootdist = gets(kv, "rootdist");
+    user_data d;
+    d.read_datafiles(p);
+    if (geti(kv, "rootfilter", 1)) {    // cafexp.cpp:189-199
+        auto rem = std::remove_if(d.gene_families.begin(), d.gene_families.end(), [&](const gene_family& fam) {
+            return !fam.exists_at_root(d.p_tree); });
+        d.gene_families.erase(rem, d.gene_families.end());
+    }
+    if (has(kv, "limit")) {
+        size_t lim = (size_t)geti(kv, "limit");
+        if (d.gene_families.size() > lim) d.gene_families.resize(lim);
+    }
+    if (has(kv, "m")) d.max_family_size = geti(kv, "m");
+    if (has(kv, "r")) d.max_root_family_size = geti(kv, "r");
+
+    std::unique_ptr<root_equilibrium_distribution> prior;
+    std::string pr = gets(kv, "prior", "uniform");
+    if (pr == "uniform") prior.reset(new uniform_distribution());
+    else prior.reset(new ::poisson_distribution(std::stod(pr.substr(pr.find(':') + 1))));
+
+    std::string mdl = gets(kv, "model", "base");
+    std::unique_ptr<model> m;
+    std::vector<double> mults;
+    if (mdl == "gamma") {
+        auto g = new gamma_model(d.p_lambda, d.p_tree, &d.gene_families, d.max_family_size, d.max_root_family_size,
+            geti(kv, "k"), getd(kv, "alpha"), d.p_error_model);
+        mults = g->get_lambda_multipliers();
+        m.reset(g);
+    } else {
+        m.reset(new base_model(d.p_lambda, d.p_tree, &d.gene_families, d.max_family_size, d.max_root_family_size, d.p_error_model));
+    }
+    int reps = geti(kv, "reps", 1);
+    double score = 0, best = 1e300;
+    for (int r = 0; r < reps; ++r) {
+        double t0 = now();
+        score = m->infer_family_likelihoods(prior.get(), d.rootdist, d.p_lambda);
+        double dt = now() - t0;
+        if (dt < best) best = dt;
+    }
+    printf("{\"neg_lnl\": "); pd(score);
+    printf(", \"n_families\": %zu, \"max_family_size\": %d, \"max_root_family_size\": %d, \"seconds\": %.6f, \"threads\": %d",
+        d.gene_families.size(), d.max_family_size, d.max_root_family_size, best, omp_get_max_threads());
+    if (!mults.empty()) { printf(", "); parr("multipliers", mults); }
+    if (geti(kv, "per_family", 0) && !std::isinf(score)) {
+        std::ostringstream ost;
+        ost.precision(17);
+        m->write_family_likelihoods(ost);
+        // base: "id\tlnL"; gamma: "id\tmult\tcatlik\tfamlik\tpost\tsig" one row per (family, category)
+        std::istringstream ist(ost.str());
+        std::string line;
+        std::getline(ist, line);
+        std::vector<double> a, b, c;
+        while (std::getline(ist, line)) {
+            std::vector<std::string> tk = tokenize_str(line, '\t');
+            if (mdl == "gamma") { a.push_back(std::stod(tk[2])); b.push_back(std::stod(tk[3])); c.push_back(std::stod(tk[4])); }
+            else a.push_back(std::stod(tk[1]));
+        }
+        if (mdl == "gamma") { printf(", "); parr("category_likelihood", a); printf(", "); parr("family_likelihood", b); printf(", "); parr("posterior", c); }
+        else { printf(", "); parr("family_lnl", a); }
+    }
+    printf("}\n");
+    return 0;
+}
+
+static int job_time_matrices(const kv_t& kv) {
+    int n = geti(kv, "n"), count = geti(kv, "count", 1);
+    double lambda = getd(kv, "lambda"), t0v = getd(kv, "t0", 1.0);
+    std::set<double> bl;
+    for (int i = 0; i < count; ++i) bl.insert(t0v + 0.731 * i);
+    matrix_cache calc(n);
+    double t0 = now();
+    calc.precalculate_matrices({ lambda }, bl);
+    double dt = now() - t0;
+    printf("{\"seconds\": %.6f, \"count\": %d, \"n\": %d, \"threads\": %d}\n", dt, count, n, omp_get_max_threads());
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: ref_harness <job> key=value...\n"); return 2; }
+    init_lgamma_cache();
+    std::string job(argv[1]);
+    kv_t kv = parse_args(argc, argv, 2);
+    try {
+        // the reference prints progress to cout (e.g. "Found root!", "Score (-lnL)") unless built -DSILENT
+        if (job == "bd") return job_bd(kv);
+        if (job == "bdlog") return job_bdlog(kv);
+        if (job == "key") return job_key(kv);
+        if (job == "matrix") return job_matrix(kv);
+        if (job == "gamma") return job_gamma(kv);
+        if (job == "prune") return job_prune(kv);
+        if (job == "score") return job_score(kv);
+        if (job == "time_matrices") return job_time_matrices(kv);
+    } catch (std::exception& e) {
+        fprintf(stderr, "ref_harness: %s\n", e.what());
+        return 1;
+    }
+    fprintf(stderr, "unknown job %s\n", job.c_str());
+    return 2;
+}
