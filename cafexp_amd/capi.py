@@ -1,0 +1,263 @@
+"""ctypes binding of libcafe_mi355x.so (the C ABI declared in include/cafe_mi355x.h).
+
+Plumbing only: builds the C structs from `problem.Problem` / `problem.Params`, calls the library
+and raises on error codes.  There is no fallback: if the HIP library is missing or no GPU is
+usable, every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .problem import Params, Problem
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcafe_mi355x.so")
+
+CAFE_MAX_CATEGORIES = 32
+CAFE_FLAG_NO_DEDUP = 1
+CAFE_MODEL_BASE, CAFE_MODEL_GAMMA = 0, 1
+
+_i32p = C.POINTER(C.c_int32)
+_f64p = C.POINTER(C.c_double)
+_f32p = C.POINTER(C.c_float)
+
+
+class CafeProblem(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_int32), ("parent", _i32p), ("branch_length", _f64p), ("lambda_index", _i32p),
+        ("leaf_taxon", _i32p), ("n_taxa", C.c_int32), ("n_families", C.c_int64), ("counts", _i32p),
+        ("max_family_size", C.c_int32), ("max_root_family_size", C.c_int32), ("n_lambdas", C.c_int32),
+        ("single_lambda", C.c_int32), ("max_categories", C.c_int32), ("n_deviations", C.c_int32),
+        ("device", C.c_int32), ("flags", C.c_int32), ("workspace_limit", C.c_size_t),
+    ]
+
+
+class CafeParams(C.Structure):
+    _fields_ = [
+        ("model", C.c_int32), ("lambdas", _f64p), ("n_categories", C.c_int32), ("multipliers", _f64p),
+        ("cat_probs", _f64p), ("alpha", C.c_double), ("prior", _f32p), ("error_model", _f64p),
+    ]
+
+
+class CafeFamilyOut(C.Structure):
+    _fields_ = [("family_lnl", _f64p), ("category_likelihood", _f64p), ("family_likelihood", _f64p), ("failed", _i32p)]
+
+
+class CafeStats(C.Structure):
+    _fields_ = [
+        ("ms_total", C.c_double), ("ms_matrices", C.c_double), ("ms_prune", C.c_double), ("ms_gemm", C.c_double),
+        ("ms_reduce", C.c_double), ("gemm_flops", C.c_double), ("gemm_bytes", C.c_double),
+        ("gemm_launches", C.c_int64), ("n_matrices", C.c_int64), ("n_unique_families", C.c_int64),
+        ("n_chunks", C.c_int64), ("matrix_bytes", C.c_int64), ("panel_bytes", C.c_int64),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+EXPORTS = [
+    "cafe_abi_version", "cafe_create", "cafe_destroy", "cafe_last_error", "cafe_score", "cafe_score_partial",
+    "cafe_finish_partial", "cafe_family_results", "cafe_get_matrix", "cafe_get_root_likelihoods", "cafe_get_stats",
+    "cafe_matrix_size", "cafe_build_matrices", "cafe_probe_fp64_mfma", "cafe_set_profiling",
+]
+
+_lib = None
+
+
+class CafeError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the HIP library; raises CafeError when it was not built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CafeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.cafe_abi_version.restype = C.c_int
+    L.cafe_create.restype = C.c_void_p
+    L.cafe_create.argtypes = [C.POINTER(CafeProblem), C.c_char_p, C.c_size_t]
+    L.cafe_destroy.argtypes = [C.c_void_p]
+    L.cafe_destroy.restype = None
+    L.cafe_last_error.restype = C.c_char_p
+    L.cafe_last_error.argtypes = [C.c_void_p]
+    L.cafe_score.restype = C.c_int
+    L.cafe_score.argtypes = [C.c_void_p, C.POINTER(CafeParams), _f64p, C.POINTER(CafeFamilyOut)]
+    L.cafe_score_partial.restype = C.c_int
+    L.cafe_score_partial.argtypes = [C.c_void_p, C.POINTER(CafeParams), C.c_void_p, C.c_void_p]
+    L.cafe_finish_partial.restype = C.c_double
+    L.cafe_finish_partial.argtypes = [_f64p]
+    L.cafe_family_results.restype = C.c_int
+    L.cafe_family_results.argtypes = [C.c_void_p, C.POINTER(CafeFamilyOut)]
+    L.cafe_get_matrix.restype = C.c_int
+    L.cafe_get_matrix.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _f64p, C.c_size_t]
+    L.cafe_get_root_likelihoods.restype = C.c_int
+    L.cafe_get_root_likelihoods.argtypes = [C.c_void_p, C.c_int64, C.c_int32, _f64p, C.c_size_t]
+    L.cafe_get_stats.restype = C.c_int
+    L.cafe_get_stats.argtypes = [C.c_void_p, C.POINTER(CafeStats)]
+    L.cafe_matrix_size.restype = C.c_int
+    L.cafe_matrix_size.argtypes = [C.c_void_p]
+    L.cafe_build_matrices.restype = C.c_int
+    L.cafe_build_matrices.argtypes = [C.c_int32, C.c_int32, C.c_int32, _f64p, _f64p, _f64p]
+    L.cafe_probe_fp64_mfma.restype = C.c_int
+    L.cafe_probe_fp64_mfma.argtypes = [C.c_int32, _f64p]
+    L.cafe_set_profiling.restype = C.c_int
+    L.cafe_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    _lib = L
+    return L
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+class Context:
+    """One cafe_ctx: a family shard resident on one GPU (model state of the reference's scorer)."""
+
+    def __init__(self, pb: Problem, max_categories: int = 1, device: int = 0, dedup: bool = True,
+                 workspace_limit: int = 0):
+        self._lib = load()
+        self._keep = []
+        k = self._c
+        cp = CafeProblem()
+        cp.n_nodes = pb.n_nodes
+        cp.parent = _p(k(pb.parent, np.int32), _i32p)
+        cp.branch_length = _p(k(pb.branch_length, np.float64), _f64p)
+        cp.lambda_index = _p(k(pb.lambda_index, np.int32), _i32p)
+        cp.leaf_taxon = _p(k(pb.leaf_taxon, np.int32), _i32p)
+        cp.n_taxa = pb.n_taxa
+        cp.n_families = pb.n_families
+        cp.counts = _p(k(pb.counts, np.int32), _i32p)
+        cp.max_family_size = pb.max_family_size
+        cp.max_root_family_size = pb.max_root_family_size
+        cp.n_lambdas = pb.n_lambdas
+        cp.single_lambda = 1 if pb.single_lambda else 0
+        cp.max_categories = max_categories
+        cp.n_deviations = pb.n_deviations
+        cp.device = device
+        cp.flags = 0 if dedup else CAFE_FLAG_NO_DEDUP
+        cp.workspace_limit = workspace_limit
+        err = C.create_string_buffer(512)
+        self._h = self._lib.cafe_create(C.byref(cp), err, 512)
+        if not self._h:
+            raise CafeError(err.value.decode() or "cafe_create failed")
+        self.problem = pb
+        self.R = pb.max_root_family_size
+        self.n_families = pb.n_families
+        self._keep = []          # cafe_create copied everything
+
+    def _c(self, a, dt):
+        a = np.ascontiguousarray(a, dtype=dt)
+        self._keep.append(a)
+        return a
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cafe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise CafeError("code %d: %s" % (rc, self._lib.cafe_last_error(self._h).decode()))
+
+    def _params(self, pr: Params, alpha: float = 1.0):
+        keep = []
+
+        def k(a, dt):
+            a = np.ascontiguousarray(a, dtype=dt)
+            keep.append(a)
+            return a
+        cp = CafeParams()
+        cp.model = CAFE_MODEL_GAMMA if pr.multipliers is not None else CAFE_MODEL_BASE
+        cp.lambdas = _p(k(pr.lambdas, np.float64), _f64p)
+        if pr.multipliers is not None:
+            cp.n_categories = len(pr.multipliers)
+            cp.multipliers = _p(k(pr.multipliers, np.float64), _f64p)
+            cp.cat_probs = _p(k(pr.cat_probs, np.float64), _f64p)
+        else:
+            cp.n_categories = 1
+        cp.alpha = alpha
+        cp.prior = _p(k(pr.prior, np.float32), _f32p)
+        cp.error_model = _p(k(pr.error_model, np.float64), _f64p) if pr.error_model is not None else None
+        return cp, keep
+
+    def score(self, pr: Params, alpha: float = 1.0, per_family: bool = False):
+        """One infer_family_likelihoods call -> -lnL (float, may be inf / nan)."""
+        cp, keep = self._params(pr, alpha)
+        out = C.c_double()
+        self._check(self._lib.cafe_score(self._h, C.byref(cp), C.byref(out), None))
+        if not per_family:
+            return out.value
+        return out.value, self.family_results(len(pr.multipliers) if pr.multipliers is not None else 0)
+
+    def family_results(self, K: int = 0):
+        F = self.n_families
+        fo = CafeFamilyOut()
+        res = {"family_lnl": np.empty(F), "failed": np.empty(F, dtype=np.int32)}
+        fo.family_lnl = _p(res["family_lnl"], _f64p)
+        fo.failed = _p(res["failed"], _i32p)
+        if K > 0:
+            res["category_likelihood"] = np.empty((F, K))
+            res["family_likelihood"] = np.empty(F)
+            fo.category_likelihood = _p(res["category_likelihood"], _f64p)
+            fo.family_likelihood = _p(res["family_likelihood"], _f64p)
+        self._check(self._lib.cafe_family_results(self._h, C.byref(fo)))
+        return res
+
+    def score_partial(self, pr: Params, device_ptr: int, stream: int = 0, alpha: float = 1.0):
+        """Enqueue the shard's work; {sum lnL, rejects} lands in 2 doubles of device memory."""
+        cp, keep = self._params(pr, alpha)
+        self._check(self._lib.cafe_score_partial(self._h, C.byref(cp), C.c_void_p(device_ptr), C.c_void_p(stream)))
+
+    def finish(self, host_pair) -> float:
+        a = np.ascontiguousarray(host_pair, dtype=np.float64)
+        return self._lib.cafe_finish_partial(_p(a, _f64p))
+
+    def matrix(self, node: int, category: int = 0) -> np.ndarray:
+        n = self._lib.cafe_matrix_size(self._h)
+        out = np.empty((n, n))
+        self._check(self._lib.cafe_get_matrix(self._h, node, category, _p(out, _f64p), out.size))
+        return out
+
+    def root_likelihoods(self, family: int, category: int = 0) -> np.ndarray:
+        out = np.empty(self.R)
+        self._check(self._lib.cafe_get_root_likelihoods(self._h, family, category, _p(out, _f64p), out.size))
+        return out
+
+    def stats(self) -> dict:
+        st = CafeStats()
+        self._check(self._lib.cafe_get_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def set_profiling(self, on: bool):
+        self._check(self._lib.cafe_set_profiling(self._h, 1 if on else 0))
+
+
+def build_matrices(n: int, lambdas, ts, device: int = 0) -> np.ndarray:
+    lam = np.ascontiguousarray(lambdas, dtype=np.float64)
+    t = np.ascontiguousarray(ts, dtype=np.float64)
+    out = np.empty((len(lam), n, n))
+    rc = load().cafe_build_matrices(device, n, len(lam), _p(lam, _f64p), _p(t, _f64p), _p(out, _f64p))
+    if rc:
+        raise CafeError("cafe_build_matrices failed with code %d" % rc)
+    return out
+
+
+def probe_fp64_mfma(device: int = 0) -> float:
+    v = C.c_double()
+    rc = load().cafe_probe_fp64_mfma(device, C.byref(v))
+    if rc:
+        raise CafeError("cafe_probe_fp64_mfma failed with code %d" % rc)
+    return v.value

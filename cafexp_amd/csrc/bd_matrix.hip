@@ -1,0 +1,131 @@
+// K1 bd_matrix_build: all birth-death transition matrices of one scorer call.
+//
+// Replaces matrix_cache::precalculate_matrices (src/matrix_cache.cpp:121-171) and, entry by
+// entry, the_probability_of_going_from_parent_fam_size_to_c (src/probability.cpp:147) /
+// birthdeath_rate_with_log_alpha (src/probability.cpp:101).  The reference evaluates every
+// entry as a log-space sum of min(s,c)+1 terms (O(N^3) per matrix).  The closed form it sums is
+// the s-fold convolution of the single-lineage law of the critical linear birth-death process,
+//     p1(0) = a,   p1(k) = (1-a)^2 a^(k-1)  (k >= 1),    a = lambda t / (1 + lambda t),
+// so row s = row s-1 (*) p1, which is a first-order linear recurrence along the row:
+//     h(c) = P[s-1][c-1] + a h(c-1),        P[s][c] = a P[s-1][c] + (1-a)^2 h(c).
+// All terms are non-negative (no cancellation), O(N^2) per matrix.  The reference's special
+// cases are kept: row 0 = e_0 (matrix_cache.cpp:70-77), saturated or degenerate coeff => rows
+// s >= 1 are zero (matrix_cache.cpp:153, probability.cpp:154), values clamped to [0,1]
+// (probability.cpp:145).
+//
+// Mapping: ONE 64-lane wave per matrix.  Lane l owns E consecutive columns of the current row
+// in registers; a row step is E local FMAs, a 6-step Kogge-Stone scan over the 64 lane
+// aggregates with the constant ratio a^E (DPP/permute shuffles, no LDS, no barrier), and E
+// fix-up FMAs.  The N-1 row steps are sequential; the grid has one wave per (branch, category)
+// matrix, so a call with hundreds of matrices fills the chip.  Bound: HBM write of the pool
+// (8*N*ld bytes per matrix), see DESIGN.md.
+#include "cafe_kernels.h"
+
+namespace cafe {
+
+template <int E>
+__global__ __launch_bounds__(64) void bd_matrix_build_kernel(MatrixPool pool, const SlotParam* __restrict__ slots, int n_slots) {
+    const int lane = threadIdx.x;
+    const int slot = blockIdx.x;
+    if (slot >= n_slots) return;
+    const SlotParam sp = slots[slot];
+    double* __restrict__ P = pool.base + (int64_t)slot * pool.stride;
+    const int n = pool.n, ld = pool.ld;
+    const int c0 = lane * E;
+    const double a = sp.alpha, q = sp.oma2;
+
+    double apow[E];                      // a^(i+1)
+    apow[0] = a;
+#pragma unroll
+    for (int i = 1; i < E; ++i) apow[i] = apow[i - 1] * a;
+    double ratio[6];                     // (a^E)^(2^d)
+    ratio[0] = apow[E - 1];
+#pragma unroll
+    for (int d = 1; d < 6; ++d) ratio[d] = ratio[d - 1] * ratio[d - 1];
+
+    double p[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) p[i] = (c0 + i == 0) ? 1.0 : 0.0;
+
+    auto store_row = [&](int s) {
+        double* row = P + (int64_t)s * ld + c0;
+        if constexpr (E % 2 == 0) {
+#pragma unroll
+            for (int i = 0; i < E; i += 2) {
+                if (c0 + i < ld) {       // ld is even, c0+i is even: the pair is in or out together
+                    double2 v;
+                    v.x = (c0 + i < n) ? p[i] : 0.0;
+                    v.y = (c0 + i + 1 < n) ? p[i + 1] : 0.0;
+                    *reinterpret_cast<double2*>(row + i) = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < E; ++i)
+                if (c0 + i < ld) row[i] = (c0 + i < n) ? p[i] : 0.0;
+        }
+    };
+
+    store_row(0);
+    if (sp.zero) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) p[i] = 0.0;
+        for (int s = 1; s < n; ++s) store_row(s);
+        return;
+    }
+
+    for (int s = 1; s < n; ++s) {
+        double left = __shfl_up(p[E - 1], 1);
+        if (lane == 0) left = 0.0;
+        double h[E];
+        h[0] = left;
+#pragma unroll
+        for (int i = 1; i < E; ++i) h[i] = fma(a, h[i - 1], p[i - 1]);
+        // inclusive scan of the lane totals with ratio a^E
+        double S = h[E - 1];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) {
+            double up = __shfl_up(S, 1 << d);
+            if (lane >= (1 << d)) S = fma(ratio[d], up, S);
+        }
+        double carry = __shfl_up(S, 1);
+        if (lane == 0) carry = 0.0;
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            double hh = fma(apow[i], carry, h[i]);
+            double v = fma(a, p[i], q * hh);
+            v = v < 1.0 ? v : 1.0;
+            p[i] = v > 0.0 ? v : 0.0;
+        }
+        store_row(s);
+    }
+}
+
+int bd_matrix_max_order() { return 64 * 32; }
+
+hipError_t launch_bd_matrix_build(const MatrixPool& pool, const SlotParam* d_slots, int n_slots, hipStream_t stream) {
+    if (n_slots <= 0) return hipSuccess;
+    if (pool.ld > bd_matrix_max_order() || (pool.ld & 1)) return hipErrorInvalidValue;
+    dim3 grid(n_slots), block(64);
+#define CAFE_BD_CASE(EV)                                                                              \
+    if (pool.ld <= 64 * EV) {                                                                         \
+        hipLaunchKernelGGL(bd_matrix_build_kernel<EV>, grid, block, 0, stream, pool, d_slots, n_slots); \
+        return hipGetLastError();                                                                     \
+    }
+    CAFE_BD_CASE(2)
+    CAFE_BD_CASE(4)
+    CAFE_BD_CASE(6)
+    CAFE_BD_CASE(8)
+    CAFE_BD_CASE(10)
+    CAFE_BD_CASE(12)
+    CAFE_BD_CASE(14)
+    CAFE_BD_CASE(16)
+    CAFE_BD_CASE(20)
+    CAFE_BD_CASE(24)
+    CAFE_BD_CASE(28)
+    CAFE_BD_CASE(32)
+#undef CAFE_BD_CASE
+    return hipErrorInvalidValue;
+}
+
+}  // namespace cafe

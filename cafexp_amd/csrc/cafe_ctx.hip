@@ -1,0 +1,783 @@
+// Host side of the C ABI (include/cafe_mi355x.h): context, schedule, per-call enqueue.
+//
+// What of the reference this replaces, per scorer call:
+//   base_model::infer_family_likelihoods   src/base_model.cpp:53-112
+//   gamma_model::infer_family_likelihoods  src/gamma_core.cpp:169-246 (+ can_infer :123)
+//   matrix_cache / matrix_cache_key        src/matrix_cache.h:42-61, src/matrix_cache.cpp:99-171
+//   inference_prune                        src/core.cpp:133-144
+// The tree is flattened once into a schedule of leaf-gather and GEMM launches (post-order,
+// Sethi-Ullman child order so that few likelihood panels are live), families are de-duplicated
+// once (build_reference_list, base_model.cpp:27) and stay resident on the device; a call uploads
+// only the scalars that prepare_calculation changes.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/cafe_mi355x.h"
+#include "cafe_kernels.h"
+
+using namespace cafe;
+
+namespace {
+
+struct Op {
+    int type;                   // 0 gather, 1 gemm
+    int dst_panel;
+    int src_panel;              // gemm
+    int child;                  // gemm: child node (its branch's matrix)
+    int n_leaf;                 // gather
+    int leaf_node[kMaxLeafPerOp];
+    int mode;                   // 0 store, 1 multiply
+    bool to_root;
+};
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline int64_t round_up64(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+struct cafe_ctx {
+    // problem
+    int n_nodes = 0, n_taxa = 0, M = 0, R = 0, N = 0, n_lambdas = 1, single_lambda = 1, Kmax = 1, n_dev = 0, device = 0;
+    int root = -1;
+    std::vector<int> parent, lam_idx, leaf_taxon;
+    std::vector<double> blen;
+    std::vector<std::vector<int>> children;
+    int64_t F_all = 0, F_uniq = 0, Fp = 0;
+    std::vector<int64_t> ref_of;            // family -> unique column
+    std::vector<double> weights;
+
+    // schedule
+    std::vector<Op> ops;
+    int n_panels = 0, root_panel = -1;
+
+    // device state
+    hipStream_t stream = nullptr;
+    hipStream_t last_stream = nullptr;       // stream the last call was enqueued on
+    int32_t* d_counts = nullptr;
+    double* d_weights = nullptr;
+    MatrixPool pool{nullptr, 0, 0, 0};
+    int max_slots = 0;
+    SlotParam* d_slots = nullptr;
+    double* d_panels = nullptr;
+    int64_t panel_stride = 0;               // doubles per panel
+    int64_t panel_kstride = 0;              // doubles per category inside a panel
+    int rows_pad = 0, kc = 0;
+    int64_t chunk_cols = 0;
+    double *d_prior = nullptr, *d_logprior = nullptr, *d_catprobs = nullptr, *d_err = nullptr;
+    double *d_fam_out = nullptr, *d_fam_lik = nullptr, *d_cat_out = nullptr;
+    int32_t* d_failed = nullptr;
+    double* d_scratch = nullptr;
+    int n_scratch = 1024;
+    double* d_result = nullptr;
+    // pinned staging
+    char* h_stage = nullptr;
+    size_t stage_bytes = 0;
+    double* h_result = nullptr;
+    hipEvent_t ev_upload = nullptr;
+    bool upload_pending = false;
+
+    // last call
+    std::vector<int> slot_of;               // [node*Kmax + k]
+    int K_last = 0, model_last = -1;
+    bool last_rejected = false, have_results = false;
+    int n_slots_last = 0;
+    int64_t last_chunk_f0 = 0, last_chunk_nf = 0;
+
+    // measurement
+    int profile = 1;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> gemm_ev;
+    size_t gemm_ev_used = 0;
+    bool events_valid = false;
+    cafe_stats stats{};
+
+    std::string err;
+};
+
+namespace {
+
+void set_err(cafe_ctx* c, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    c->err = buf;
+}
+
+#define HIP_TRY(c, expr)                                                                    \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            set_err(c, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return CAFE_ERR_DEVICE;                                                         \
+        }                                                                                   \
+    } while (0)
+
+// Sethi-Ullman style need: panels live while evaluating node v (leaves need none).
+int panel_need(const cafe_ctx* c, int v, std::vector<int>& need) {
+    std::vector<int> kid;
+    for (int u : c->children[v])
+        if (c->leaf_taxon[u] < 0) kid.push_back(panel_need(c, u, need));
+    std::sort(kid.begin(), kid.end(), std::greater<int>());
+    int n = (int)kid.size() + 1;
+    for (size_t i = 0; i < kid.size(); ++i) n = std::max(n, (int)i + kid[i]);
+    need[v] = n;
+    return n;
+}
+
+struct PanelAlloc {
+    std::vector<int> free_list;
+    int high = 0;
+    int get() {
+        if (!free_list.empty()) { int p = free_list.back(); free_list.pop_back(); return p; }
+        return high++;
+    }
+    void put(int p) { free_list.push_back(p); }
+};
+
+int emit_node(cafe_ctx* c, int v, const std::vector<int>& need, PanelAlloc& pa) {
+    std::vector<int> inner, leaves;
+    for (int u : c->children[v]) (c->leaf_taxon[u] < 0 ? inner : leaves).push_back(u);
+    std::vector<int> order = inner;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return need[x] > need[y]; });
+    std::map<int, int> panel_of;
+    for (int u : order) panel_of[u] = emit_node(c, u, need, pa);
+    const int dst = pa.get();
+    bool init = false;
+    for (size_t i = 0; i < leaves.size(); i += kMaxLeafPerOp) {
+        Op op{};
+        op.type = 0;
+        op.dst_panel = dst;
+        op.n_leaf = (int)std::min<size_t>(kMaxLeafPerOp, leaves.size() - i);
+        for (int l = 0; l < op.n_leaf; ++l) op.leaf_node[l] = leaves[i + l];
+        op.mode = init ? 1 : 0;
+        op.to_root = (v == c->root);
+        c->ops.push_back(op);
+        init = true;
+    }
+    for (int u : inner) {      // child order of the reference (probability.cpp:205 walks _descendants in order)
+        Op op{};
+        op.type = 1;
+        op.dst_panel = dst;
+        op.src_panel = panel_of[u];
+        op.child = u;
+        op.mode = init ? 1 : 0;
+        op.to_root = (v == c->root);
+        c->ops.push_back(op);
+        init = true;
+    }
+    for (int u : inner) pa.put(panel_of[u]);
+    return dst;
+}
+
+// matrix_cache_key (matrix_cache.h:42-61)
+inline void quantize(double lambda, double t, long* lq, long* tq) {
+    *lq = long(lambda * 1000000000);
+    *tq = long(t * 1000);
+}
+
+void free_device(cafe_ctx* c) {
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    hipFree(c->d_counts); hipFree(c->d_weights); hipFree(c->pool.base); hipFree(c->d_slots); hipFree(c->d_panels);
+    hipFree(c->d_prior); hipFree(c->d_logprior); hipFree(c->d_catprobs); hipFree(c->d_err);
+    hipFree(c->d_fam_out); hipFree(c->d_fam_lik); hipFree(c->d_cat_out); hipFree(c->d_failed);
+    hipFree(c->d_scratch); hipFree(c->d_result);
+    if (c->h_stage) hipHostFree(c->h_stage);
+    if (c->h_result) hipHostFree(c->h_result);
+    if (c->ev_upload) hipEventDestroy(c->ev_upload);
+    for (auto& e : c->ev) if (e) hipEventDestroy(e);
+    for (auto& e : c->gemm_ev) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+}
+
+int create_impl(cafe_ctx* c, const cafe_problem* p) {
+    if (!p || p->n_nodes < 3 || !p->parent || !p->branch_length || !p->leaf_taxon || !p->counts) {
+        set_err(c, "cafe_create: missing tree or family arrays");
+        return CAFE_ERR_ARGUMENT;
+    }
+    if (p->n_families < 1 || p->n_taxa < 2 || p->max_family_size < 1 || p->max_root_family_size < 1) {
+        set_err(c, "cafe_create: empty family table or non-positive max sizes");
+        return CAFE_ERR_ARGUMENT;
+    }
+    c->n_nodes = p->n_nodes; c->n_taxa = p->n_taxa; c->M = p->max_family_size; c->R = p->max_root_family_size;
+    c->N = std::max(c->M, c->R) + 1;                                   // base_model.cpp:77
+    c->n_lambdas = std::max(1, p->n_lambdas); c->single_lambda = p->single_lambda;
+    c->Kmax = std::max(1, p->max_categories); c->n_dev = p->n_deviations; c->device = p->device;
+    if (c->Kmax > CAFE_MAX_CATEGORIES) { set_err(c, "cafe_create: more than %d gamma categories", CAFE_MAX_CATEGORIES); return CAFE_ERR_ARGUMENT; }
+    c->parent.assign(p->parent, p->parent + p->n_nodes);
+    c->blen.assign(p->branch_length, p->branch_length + p->n_nodes);
+    c->leaf_taxon.assign(p->leaf_taxon, p->leaf_taxon + p->n_nodes);
+    if (p->lambda_index) c->lam_idx.assign(p->lambda_index, p->lambda_index + p->n_nodes);
+    else c->lam_idx.assign(p->n_nodes, 0);
+    c->children.assign(p->n_nodes, {});
+    for (int v = 0; v < p->n_nodes; ++v) {
+        int par = c->parent[v];
+        if (par < 0) {
+            if (c->root >= 0) { set_err(c, "cafe_create: more than one root"); return CAFE_ERR_ARGUMENT; }
+            c->root = v;
+        } else if (par >= p->n_nodes || par <= v) {
+            set_err(c, "cafe_create: node %d: parent %d must come after its children", v, par);
+            return CAFE_ERR_ARGUMENT;
+        } else {
+            c->children[par].push_back(v);
+        }
+        if (c->lam_idx[v] < 0 || c->lam_idx[v] >= c->n_lambdas) { set_err(c, "cafe_create: lambda index out of range at node %d", v); return CAFE_ERR_ARGUMENT; }
+    }
+    if (c->root < 0) { set_err(c, "cafe_create: no root"); return CAFE_ERR_ARGUMENT; }
+    for (int v = 0; v < p->n_nodes; ++v) {
+        bool leaf = c->children[v].empty();
+        if (leaf != (c->leaf_taxon[v] >= 0) || (leaf && c->leaf_taxon[v] >= c->n_taxa)) {
+            set_err(c, "cafe_create: leaf_taxon inconsistent with the tree at node %d", v);
+            return CAFE_ERR_ARGUMENT;
+        }
+    }
+    if (c->children[c->root].empty()) { set_err(c, "cafe_create: the root is a leaf"); return CAFE_ERR_ARGUMENT; }
+    if (c->N > bd_matrix_max_order()) { set_err(c, "cafe_create: matrix order %d exceeds %d", c->N, bd_matrix_max_order()); return CAFE_ERR_ARGUMENT; }
+
+    // families: range check + de-duplication (build_reference_list, base_model.cpp:27-51)
+    c->F_all = p->n_families;
+    const int T = c->n_taxa;
+    for (int64_t i = 0; i < c->F_all * T; ++i)
+        if (p->counts[i] < 0 || p->counts[i] > c->M) {
+            set_err(c, "cafe_create: family %lld has a count outside [0, %d]", (long long)(i / T), c->M);
+            return CAFE_ERR_ARGUMENT;
+        }
+    c->ref_of.resize(c->F_all);
+    std::vector<int64_t> uniq;                 // first occurrence of each distinct row
+    if (p->flags & CAFE_FLAG_NO_DEDUP) {
+        uniq.resize(c->F_all);
+        for (int64_t f = 0; f < c->F_all; ++f) { uniq[f] = f; c->ref_of[f] = f; }
+        c->weights.assign(c->F_all, 1.0);
+    } else {
+        std::unordered_map<std::string, int64_t> seen;
+        seen.reserve((size_t)c->F_all * 2);
+        for (int64_t f = 0; f < c->F_all; ++f) {
+            std::string key(reinterpret_cast<const char*>(p->counts + f * T), sizeof(int32_t) * T);
+            auto it = seen.find(key);
+            if (it == seen.end()) {
+                seen.emplace(std::move(key), (int64_t)uniq.size());
+                c->ref_of[f] = (int64_t)uniq.size();
+                uniq.push_back(f);
+                c->weights.push_back(1.0);
+            } else {
+                c->ref_of[f] = it->second;
+                c->weights[it->second] += 1.0;
+            }
+        }
+    }
+    c->F_uniq = (int64_t)uniq.size();
+    c->Fp = round_up64(c->F_uniq, kBN);
+
+    // schedule
+    std::vector<int> need(c->n_nodes, 0);
+    panel_need(c, c->root, need);
+    PanelAlloc pa;
+    c->root_panel = emit_node(c, c->root, need, pa);
+    c->n_panels = pa.high;
+
+    // device
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_err(c, "cafe_create: no HIP device available (this library has no CPU path)"); return CAFE_ERR_DEVICE; }
+    if (c->device < 0 || c->device >= ndev) { set_err(c, "cafe_create: device %d out of range (%d devices)", c->device, ndev); return CAFE_ERR_DEVICE; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+
+    // counts, taxon-major, padded families replicate an all-zero family
+    {
+        std::vector<int32_t> tm((size_t)T * c->Fp, 0);
+        for (int64_t u = 0; u < c->F_uniq; ++u)
+            for (int t = 0; t < T; ++t) tm[(size_t)t * c->Fp + u] = p->counts[uniq[u] * T + t];
+        HIP_TRY(c, hipMalloc(&c->d_counts, tm.size() * sizeof(int32_t)));
+        HIP_TRY(c, hipMemcpy(c->d_counts, tm.data(), tm.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        std::vector<double> w(c->Fp, 0.0);
+        std::copy(c->weights.begin(), c->weights.end(), w.begin());
+        HIP_TRY(c, hipMalloc(&c->d_weights, w.size() * sizeof(double)));
+        HIP_TRY(c, hipMemcpy(c->d_weights, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+
+    // matrix pool: one slot per (branch, category); distinct quantized keys share a slot per call
+    c->pool.n = c->N;
+    c->pool.ld = round_up(c->N, 16);
+    c->pool.stride = (int64_t)c->N * c->pool.ld;
+    c->max_slots = (c->n_nodes - 1) * c->Kmax;
+    const size_t pool_bytes = (size_t)c->max_slots * c->pool.stride * sizeof(double);
+    if (hipMalloc(&c->pool.base, pool_bytes) != hipSuccess) {
+        set_err(c, "cafe_create: cannot allocate %.2f GB for %d transition matrices of order %d", pool_bytes / 1e9, c->max_slots, c->N);
+        return CAFE_ERR_MEMORY;
+    }
+    HIP_TRY(c, hipMalloc(&c->d_slots, sizeof(SlotParam) * c->max_slots));
+    c->stats.matrix_bytes = (int64_t)pool_bytes;
+
+    // per-call parameter block
+    HIP_TRY(c, hipMalloc(&c->d_prior, sizeof(double) * c->R));
+    HIP_TRY(c, hipMalloc(&c->d_logprior, sizeof(double) * c->R));
+    HIP_TRY(c, hipMalloc(&c->d_catprobs, sizeof(double) * c->Kmax));
+    if (c->n_dev > 0) HIP_TRY(c, hipMalloc(&c->d_err, sizeof(double) * (size_t)(c->M + 1) * c->n_dev));
+    c->stage_bytes = sizeof(SlotParam) * c->max_slots + sizeof(double) * (2 * (size_t)c->R + c->Kmax + (size_t)(c->M + 1) * std::max(1, c->n_dev)) + 64;
+    HIP_TRY(c, hipHostMalloc(&c->h_stage, c->stage_bytes, hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc(&c->h_result, 2 * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
+    for (auto& e : c->ev) HIP_TRY(c, hipEventCreate(&e));
+
+    // outputs
+    HIP_TRY(c, hipMalloc(&c->d_fam_out, sizeof(double) * c->Fp));
+    HIP_TRY(c, hipMalloc(&c->d_fam_lik, sizeof(double) * c->Fp));
+    HIP_TRY(c, hipMalloc(&c->d_cat_out, sizeof(double) * c->Fp * c->Kmax));
+    HIP_TRY(c, hipMalloc(&c->d_failed, sizeof(int32_t) * c->Fp));
+    HIP_TRY(c, hipMemset(c->d_failed, 0, sizeof(int32_t) * c->Fp));
+    HIP_TRY(c, hipMalloc(&c->d_scratch, sizeof(double) * 2 * c->n_scratch));
+    HIP_TRY(c, hipMalloc(&c->d_result, sizeof(double) * 2));
+
+    // likelihood panels: rows padded so that every panel can be a GEMM B operand (kc rows) or the root (R rows)
+    c->kc = round_up(c->M + 1, kBK);
+    c->rows_pad = std::max(c->kc, round_up(c->R, kBK));
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
+    size_t budget = p->workspace_limit ? p->workspace_limit : (size_t)(free_b * 0.80);
+    const size_t per_col = (size_t)c->n_panels * c->Kmax * c->rows_pad * sizeof(double);
+    int64_t cols = (int64_t)(budget / per_col) / kBN * kBN;
+    if (cols < kBN) { set_err(c, "cafe_create: %zu bytes of workspace cannot hold %d panels of one 128-family tile", budget, c->n_panels); return CAFE_ERR_MEMORY; }
+    c->chunk_cols = std::min<int64_t>(cols, c->Fp);
+    c->panel_kstride = (int64_t)c->rows_pad * c->chunk_cols;
+    c->panel_stride = c->panel_kstride * c->Kmax;
+    const size_t panel_bytes = (size_t)c->n_panels * c->panel_stride * sizeof(double);
+    if (hipMalloc(&c->d_panels, panel_bytes) != hipSuccess) {
+        set_err(c, "cafe_create: cannot allocate %.2f GB of likelihood panels", panel_bytes / 1e9);
+        return CAFE_ERR_MEMORY;
+    }
+    // rows beyond what the first writer of a panel covers must not hold NaN bit patterns
+    HIP_TRY(c, hipMemset(c->d_panels, 0, panel_bytes));
+    c->stats.panel_bytes = (int64_t)panel_bytes;
+    c->stats.n_unique_families = c->F_uniq;
+    c->stats.n_chunks = (c->Fp + c->chunk_cols - 1) / c->chunk_cols;
+
+    int n_gemm = 0;
+    for (auto& op : c->ops) n_gemm += op.type == 1;
+    c->gemm_ev.resize((size_t)2 * n_gemm * c->stats.n_chunks);
+    for (auto& e : c->gemm_ev) HIP_TRY(c, hipEventCreate(&e));
+    c->slot_of.assign((size_t)c->n_nodes * c->Kmax, -1);
+    HIP_TRY(c, hipDeviceSynchronize());
+    return CAFE_OK;
+}
+
+bool lambdas_valid(const cafe_ctx* c, const double* lam) {
+    if (c->single_lambda) return lam[0] > 0;                                   // lambda.h:58
+    for (int i = 0; i < c->n_lambdas; ++i) if (lam[i] < 0) return false;       // lambda.cpp:59
+    return true;
+}
+
+// Host-only rejections; true => the call's value is +inf without touching the device.
+bool rejected(const cafe_ctx* c, const cafe_params* pr, int K) {
+    if (!lambdas_valid(c, pr->lambdas)) return true;                           // base_model.cpp:56 / gamma_core.cpp:125
+    if (pr->model != CAFE_MODEL_GAMMA) return false;
+    if (pr->alpha < 0) return true;                                            // gamma_core.cpp:128
+    // gamma_core.cpp:131-139: longest branch x largest multiplier x largest lambda saturated?
+    bool first = true;
+    double longest = 0;
+    for (int v = 0; v < c->n_nodes; ++v) {       // clade::get_branch_lengths: the set of t > 0, root included
+        double t = c->blen[v];
+        if (!(t > 0.0)) continue;
+        if (first || t > longest) { longest = t; first = false; }
+    }
+    double lm = *std::max_element(pr->multipliers, pr->multipliers + K);
+    double ll = *std::max_element(pr->lambdas, pr->lambdas + c->n_lambdas);
+    double lambda = lm * ll;
+    double alpha = lambda * longest / (1 + lambda * longest);                  // matrix_cache.cpp:115
+    return (1 - 2 * alpha) < 0;
+}
+
+int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s) {
+    if (!pr || !pr->lambdas || !pr->prior) { set_err(c, "cafe_score: lambdas and prior are required"); return CAFE_ERR_ARGUMENT; }
+    const bool gamma = pr->model == CAFE_MODEL_GAMMA;
+    const int K = gamma ? pr->n_categories : 1;
+    if (gamma && (K < 1 || K > c->Kmax || !pr->multipliers || !pr->cat_probs)) {
+        set_err(c, "cafe_score: gamma model needs 1..%d categories with multipliers and cat_probs", c->Kmax);
+        return CAFE_ERR_ARGUMENT;
+    }
+    if ((c->n_dev > 0) != (pr->error_model != nullptr)) {
+        set_err(c, "cafe_score: error model %s but the problem was created with n_deviations=%d", pr->error_model ? "given" : "missing", c->n_dev);
+        return CAFE_ERR_ARGUMENT;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->last_stream = s;
+    if (c->upload_pending) { HIP_TRY(c, hipEventSynchronize(c->ev_upload)); c->upload_pending = false; }
+    c->have_results = false;
+    c->events_valid = false;
+    c->K_last = K;
+    c->model_last = pr->model;
+    c->stats.gemm_flops = c->stats.gemm_bytes = 0;
+    c->stats.gemm_launches = 0;
+
+    c->last_rejected = rejected(c, pr, K);
+    if (c->last_rejected) {
+        double* hr = reinterpret_cast<double*>(c->h_stage);
+        hr[0] = 0.0; hr[1] = 1.0;
+        HIP_TRY(c, hipMemcpyAsync(d_out, hr, 2 * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipEventRecord(c->ev_upload, s));
+        c->upload_pending = true;
+        c->stats.n_matrices = 0;
+        return CAFE_OK;
+    }
+
+    // ---- matrix keys: one slot per distinct (lambda_q, t_q); de-quantized like matrix_cache.cpp:148-149
+    char* st = c->h_stage;
+    SlotParam* h_slots = reinterpret_cast<SlotParam*>(st);
+    std::map<std::pair<long, long>, int> key_slot;
+    int n_slots = 0;
+    for (int v = 0; v < c->n_nodes; ++v) {
+        if (v == c->root) continue;
+        for (int k = 0; k < K; ++k) {
+            const double mult = gamma ? pr->multipliers[k] : 1.0;
+            const double lam = pr->lambdas[c->lam_idx[v]] * mult;               // lambda.h:39, :82-88
+            long lq, tq;
+            quantize(lam, c->blen[v], &lq, &tq);
+            auto key = std::make_pair(tq, lq);
+            auto it = key_slot.find(key);
+            int slot;
+            if (it == key_slot.end()) {
+                slot = n_slots++;
+                key_slot.emplace(key, slot);
+                const double lambda_q = double(lq) / 1000000000.0, t_q = double(tq) / 1000.0;
+                const double alpha = lambda_q * t_q / (1 + lambda_q * t_q);
+                const double coeff = 1 - 2 * alpha;
+                SlotParam sp;
+                sp.alpha = alpha;
+                sp.oma2 = (1 - alpha) * (1 - alpha);
+                sp.zero = !(coeff > 0 && coeff != 1);       // saturated (coeff < 0) or degenerate: rows s>=1 are 0
+                sp.pad = 0;
+                h_slots[slot] = sp;
+            } else {
+                slot = it->second;
+            }
+            c->slot_of[(size_t)v * c->Kmax + k] = slot;
+        }
+    }
+    c->n_slots_last = n_slots;
+    c->stats.n_matrices = n_slots;
+    size_t off = sizeof(SlotParam) * (size_t)c->max_slots;
+    double* h_prior = reinterpret_cast<double*>(st + off); off += sizeof(double) * c->R;
+    double* h_logprior = reinterpret_cast<double*>(st + off); off += sizeof(double) * c->R;
+    double* h_cat = reinterpret_cast<double*>(st + off); off += sizeof(double) * c->Kmax;
+    double* h_err = reinterpret_cast<double*>(st + off);
+    for (int j = 0; j < c->R; ++j) {
+        const double eq = (double)pr->prior[j];           // compute() returns float (root_equilibrium_distribution.h:15)
+        h_prior[j] = eq;
+        h_logprior[j] = std::log(eq);
+    }
+    for (int k = 0; k < K; ++k) h_cat[k] = gamma ? pr->cat_probs[k] : 1.0;
+    HIP_TRY(c, hipMemcpyAsync(c->d_slots, h_slots, sizeof(SlotParam) * n_slots, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_prior, h_prior, sizeof(double) * c->R, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_logprior, h_logprior, sizeof(double) * c->R, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_catprobs, h_cat, sizeof(double) * K, hipMemcpyHostToDevice, s));
+    if (c->n_dev > 0) {
+        const size_t nb = sizeof(double) * (size_t)(c->M + 1) * c->n_dev;
+        std::memcpy(h_err, pr->error_model, nb);
+        HIP_TRY(c, hipMemcpyAsync(c->d_err, h_err, nb, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_upload, s));
+    c->upload_pending = true;
+
+    // ---- K1
+    if (c->profile) HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    HIP_TRY(c, launch_bd_matrix_build(c->pool, c->d_slots, n_slots, s));
+    if (c->profile) HIP_TRY(c, hipEventRecord(c->ev[1], s));
+
+    // ---- prune, chunk by chunk
+    c->gemm_ev_used = 0;
+    for (int64_t f0 = 0; f0 < c->Fp; f0 += c->chunk_cols) {
+        const int64_t cols = std::min<int64_t>(c->chunk_cols, c->Fp - f0);
+        for (const Op& op : c->ops) {
+            const int rows = op.to_root ? c->R : c->M + 1;
+            const int rows_store = op.to_root ? c->R : c->kc;
+            double* dst = c->d_panels + (int64_t)op.dst_panel * c->panel_stride;
+            if (op.type == 0) {
+                GatherArgs g{};
+                g.pool = c->pool;
+                g.n_leaf = op.n_leaf;
+                for (int l = 0; l < op.n_leaf; ++l) {
+                    g.taxon[l] = c->leaf_taxon[op.leaf_node[l]];
+                    for (int k = 0; k < K; ++k) g.slot[l][k] = c->slot_of[(size_t)op.leaf_node[l] * c->Kmax + k];
+                }
+                g.counts = c->d_counts; g.counts_ld = c->Fp; g.f0 = f0;
+                g.dst = dst; g.panel_kstride = c->panel_kstride; g.ld = (int)cols;
+                g.row_off = op.to_root ? 1 : 0; g.rows = rows; g.rows_store = rows_store; g.mode = op.mode;
+                g.err = c->n_dev > 0 ? c->d_err : nullptr; g.n_dev = c->n_dev; g.max_family_size = c->M;
+                HIP_TRY(c, launch_leaf_gather(g, K, s));
+            } else {
+                GemmArgs g{};
+                g.pool = c->pool;
+                for (int k = 0; k < K; ++k) g.slot[k] = c->slot_of[(size_t)op.child * c->Kmax + k];
+                g.src = c->d_panels + (int64_t)op.src_panel * c->panel_stride;
+                g.dst = dst; g.panel_kstride = c->panel_kstride; g.ld = (int)cols; g.kc = c->kc;
+                g.row_off = op.to_root ? 1 : 0; g.rows = rows; g.rows_store = rows_store; g.mode = op.mode;
+                g.n_row_tiles = (rows_store + kBM - 1) / kBM;
+                g.n_col_tiles = (int)(cols / kBN);
+                if (c->profile && c->gemm_ev_used + 2 <= c->gemm_ev.size()) HIP_TRY(c, hipEventRecord(c->gemm_ev[c->gemm_ev_used++], s));
+                HIP_TRY(c, launch_prune_gemm(g, K, s));
+                if (c->profile && c->gemm_ev_used + 1 <= c->gemm_ev.size()) HIP_TRY(c, hipEventRecord(c->gemm_ev[c->gemm_ev_used++], s));
+                c->stats.gemm_launches += 1;
+                c->stats.gemm_flops += 2.0 * rows * (c->M + 1) * (double)cols * K;
+                c->stats.gemm_bytes += 8.0 * K * ((double)rows * (c->M + 1) + (double)(c->M + 1) * cols + (double)rows * cols);
+            }
+        }
+        if (c->profile && f0 + c->chunk_cols >= c->Fp) HIP_TRY(c, hipEventRecord(c->ev[2], s));
+        ReduceArgs r{};
+        r.root = c->d_panels + (int64_t)c->root_panel * c->panel_stride;
+        r.panel_kstride = c->panel_kstride; r.ld = (int)cols; r.R = c->R; r.K = K; r.model = gamma ? 1 : 0;
+        r.prior = c->d_prior; r.log_prior = c->d_logprior; r.cat_probs = c->d_catprobs;
+        r.f0 = f0; r.nf = std::max<int64_t>(0, std::min<int64_t>(cols, c->F_uniq - f0));
+        r.fam_out = c->d_fam_out; r.fam_lik = c->d_fam_lik; r.cat_out = c->d_cat_out; r.failed = c->d_failed;
+        HIP_TRY(c, launch_root_reduce(r, s));
+        c->last_chunk_f0 = f0;
+        c->last_chunk_nf = r.nf;
+    }
+    HIP_TRY(c, launch_final_sum(c->d_fam_out, c->d_weights, c->d_failed, c->F_uniq, c->d_scratch, c->n_scratch, d_out, s));
+    if (c->profile) { HIP_TRY(c, hipEventRecord(c->ev[3], s)); c->events_valid = true; }
+    c->have_results = true;
+    return CAFE_OK;
+}
+
+void collect_stats(cafe_ctx* c) {
+    if (!c->events_valid) return;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->stats.ms_matrices = ms;
+    if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->stats.ms_prune = ms;
+    if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->stats.ms_reduce = ms;
+    double g = 0;
+    for (size_t i = 0; i + 1 < c->gemm_ev_used; i += 2)
+        if (hipEventElapsedTime(&ms, c->gemm_ev[i], c->gemm_ev[i + 1]) == hipSuccess) g += ms;
+    c->stats.ms_gemm = g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cafe_abi_version(void) { return CAFE_ABI_VERSION; }
+
+cafe_ctx* cafe_create(const cafe_problem* problem, char* err, size_t errlen) {
+    cafe_ctx* c = new (std::nothrow) cafe_ctx();
+    if (!c) return nullptr;
+    int rc = CAFE_ERR_ARGUMENT;
+    try {
+        rc = create_impl(c, problem);
+    } catch (const std::exception& e) {
+        set_err(c, "cafe_create: %s", e.what());
+        rc = CAFE_ERR_MEMORY;
+    }
+    if (rc != CAFE_OK) {
+        if (err && errlen) { std::snprintf(err, errlen, "%s", c->err.c_str()); }
+        free_device(c);
+        delete c;
+        return nullptr;
+    }
+    if (err && errlen) err[0] = 0;
+    return c;
+}
+
+void cafe_destroy(cafe_ctx* ctx) {
+    if (!ctx) return;
+    free_device(ctx);
+    delete ctx;
+}
+
+const char* cafe_last_error(const cafe_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+double cafe_finish_partial(const double hp[2]) {
+    if (hp[1] > 0) return std::numeric_limits<double>::infinity();
+    return -hp[0];
+}
+
+int cafe_score_partial(cafe_ctx* ctx, const cafe_params* params, double* device_partial, void* hip_stream) {
+    if (!ctx) return CAFE_ERR_ARGUMENT;
+    if (!device_partial) { set_err(ctx, "cafe_score_partial: device_partial is NULL"); return CAFE_ERR_ARGUMENT; }
+    try {
+        return enqueue(ctx, params, device_partial, hip_stream ? (hipStream_t)hip_stream : ctx->stream);
+    } catch (const std::exception& e) {
+        set_err(ctx, "cafe_score_partial: %s", e.what());
+        return CAFE_ERR_MEMORY;
+    }
+}
+
+int cafe_score(cafe_ctx* ctx, const cafe_params* params, double* neg_lnl, const cafe_family_out* out) {
+    if (!ctx) return CAFE_ERR_ARGUMENT;
+    if (!neg_lnl) { set_err(ctx, "cafe_score: neg_lnl is NULL"); return CAFE_ERR_ARGUMENT; }
+    auto t0 = std::chrono::steady_clock::now();
+    int rc;
+    try {
+        rc = enqueue(ctx, params, ctx->d_result, ctx->stream);
+    } catch (const std::exception& e) {
+        set_err(ctx, "cafe_score: %s", e.what());
+        return CAFE_ERR_MEMORY;
+    }
+    if (rc != CAFE_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->upload_pending = false;
+    *neg_lnl = cafe_finish_partial(ctx->h_result);
+    ctx->stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    collect_stats(ctx);
+    if (out) return cafe_family_results(ctx, out);
+    return CAFE_OK;
+}
+
+int cafe_family_results(cafe_ctx* ctx, const cafe_family_out* out) {
+    if (!ctx || !out) return CAFE_ERR_ARGUMENT;
+    if (ctx->last_rejected || !ctx->have_results) {
+        // the reference leaves `results` empty / stale on a rejected call (gamma_core.cpp:173-179)
+        set_err(ctx, "cafe_family_results: the last call was rejected (+inf) or no call was made");
+        return CAFE_ERR_STATE;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+    const int K = ctx->K_last;
+    std::vector<double> tmp((size_t)ctx->F_uniq * std::max(1, K));
+    std::vector<int32_t> itmp;
+    if (out->family_lnl) {
+        HIP_TRY(ctx, hipMemcpy(tmp.data(), ctx->d_fam_out, sizeof(double) * ctx->F_uniq, hipMemcpyDeviceToHost));
+        for (int64_t f = 0; f < ctx->F_all; ++f) out->family_lnl[f] = tmp[ctx->ref_of[f]];
+    }
+    if (ctx->model_last == CAFE_MODEL_GAMMA) {
+        if (out->family_likelihood) {
+            HIP_TRY(ctx, hipMemcpy(tmp.data(), ctx->d_fam_lik, sizeof(double) * ctx->F_uniq, hipMemcpyDeviceToHost));
+            for (int64_t f = 0; f < ctx->F_all; ++f) out->family_likelihood[f] = tmp[ctx->ref_of[f]];
+        }
+        if (out->category_likelihood) {
+            HIP_TRY(ctx, hipMemcpy(tmp.data(), ctx->d_cat_out, sizeof(double) * ctx->F_uniq * K, hipMemcpyDeviceToHost));
+            for (int64_t f = 0; f < ctx->F_all; ++f)
+                for (int k = 0; k < K; ++k) out->category_likelihood[f * K + k] = tmp[ctx->ref_of[f] * K + k];
+        }
+    }
+    if (out->failed) {
+        itmp.resize(ctx->F_uniq);
+        HIP_TRY(ctx, hipMemcpy(itmp.data(), ctx->d_failed, sizeof(int32_t) * ctx->F_uniq, hipMemcpyDeviceToHost));
+        for (int64_t f = 0; f < ctx->F_all; ++f) out->failed[f] = itmp[ctx->ref_of[f]];
+    }
+    return CAFE_OK;
+}
+
+int cafe_matrix_size(const cafe_ctx* ctx) { return ctx ? ctx->N : 0; }
+
+int cafe_set_profiling(cafe_ctx* ctx, int on) {
+    if (!ctx) return CAFE_ERR_ARGUMENT;
+    ctx->profile = on ? 1 : 0;
+    return CAFE_OK;
+}
+
+int cafe_get_matrix(cafe_ctx* ctx, int32_t node, int32_t category, double* out, size_t out_len) {
+    if (!ctx || !out) return CAFE_ERR_ARGUMENT;
+    if (!ctx->have_results) { set_err(ctx, "cafe_get_matrix: no completed call"); return CAFE_ERR_STATE; }
+    if (node < 0 || node >= ctx->n_nodes || node == ctx->root || category < 0 || category >= ctx->K_last) {
+        set_err(ctx, "cafe_get_matrix: node/category out of range");
+        return CAFE_ERR_ARGUMENT;
+    }
+    const size_t n = (size_t)ctx->N;
+    if (out_len < n * n) { set_err(ctx, "cafe_get_matrix: out buffer too small"); return CAFE_ERR_ARGUMENT; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+    const int slot = ctx->slot_of[(size_t)node * ctx->Kmax + category];
+    HIP_TRY(ctx, hipMemcpy2D(out, n * sizeof(double), ctx->pool.base + (int64_t)slot * ctx->pool.stride,
+                             (size_t)ctx->pool.ld * sizeof(double), n * sizeof(double), n, hipMemcpyDeviceToHost));
+    return CAFE_OK;
+}
+
+int cafe_get_root_likelihoods(cafe_ctx* ctx, int64_t family, int32_t category, double* out, size_t out_len) {
+    if (!ctx || !out) return CAFE_ERR_ARGUMENT;
+    if (!ctx->have_results || ctx->last_rejected) { set_err(ctx, "cafe_get_root_likelihoods: no completed call"); return CAFE_ERR_STATE; }
+    if (family < 0 || family >= ctx->F_all || category < 0 || category >= ctx->K_last || out_len < (size_t)ctx->R) {
+        set_err(ctx, "cafe_get_root_likelihoods: argument out of range");
+        return CAFE_ERR_ARGUMENT;
+    }
+    const int64_t u = ctx->ref_of[family];
+    if (u < ctx->last_chunk_f0 || u >= ctx->last_chunk_f0 + ctx->last_chunk_nf) {
+        set_err(ctx, "cafe_get_root_likelihoods: family is not in the last resident chunk");
+        return CAFE_ERR_STATE;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+    const int64_t cols = std::min<int64_t>(ctx->chunk_cols, ctx->Fp - ctx->last_chunk_f0);
+    const double* src = ctx->d_panels + (int64_t)ctx->root_panel * ctx->panel_stride + (int64_t)category * ctx->panel_kstride + (u - ctx->last_chunk_f0);
+    HIP_TRY(ctx, hipMemcpy2D(out, sizeof(double), src, (size_t)cols * sizeof(double), sizeof(double), (size_t)ctx->R, hipMemcpyDeviceToHost));
+    return CAFE_OK;
+}
+
+int cafe_get_stats(const cafe_ctx* ctx, cafe_stats* stats) {
+    if (!ctx || !stats) return CAFE_ERR_ARGUMENT;
+    collect_stats(const_cast<cafe_ctx*>(ctx));
+    *stats = ctx->stats;
+    return CAFE_OK;
+}
+
+int cafe_build_matrices(int32_t device, int32_t n, int32_t count, const double* lambdas, const double* ts, double* out) {
+    if (n < 1 || count < 1 || !lambdas || !ts || !out || n > bd_matrix_max_order()) return CAFE_ERR_ARGUMENT;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return CAFE_ERR_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return CAFE_ERR_DEVICE;
+    MatrixPool pool;
+    pool.n = n; pool.ld = round_up(n, 16); pool.stride = (int64_t)n * pool.ld; pool.base = nullptr;
+    std::vector<SlotParam> sp(count);
+    for (int i = 0; i < count; ++i) {
+        long lq, tq;
+        quantize(lambdas[i], ts[i], &lq, &tq);
+        const double lambda_q = double(lq) / 1000000000.0, t_q = double(tq) / 1000.0;
+        const double alpha = lambda_q * t_q / (1 + lambda_q * t_q);
+        const double coeff = 1 - 2 * alpha;
+        sp[i].alpha = alpha; sp[i].oma2 = (1 - alpha) * (1 - alpha); sp[i].zero = !(coeff > 0 && coeff != 1); sp[i].pad = 0;
+    }
+    SlotParam* d_sp = nullptr;
+    int rc = CAFE_OK;
+    if (hipMalloc(&pool.base, sizeof(double) * pool.stride * count) != hipSuccess) return CAFE_ERR_MEMORY;
+    if (hipMalloc(&d_sp, sizeof(SlotParam) * count) != hipSuccess) { hipFree(pool.base); return CAFE_ERR_MEMORY; }
+    if (hipMemcpy(d_sp, sp.data(), sizeof(SlotParam) * count, hipMemcpyHostToDevice) != hipSuccess) rc = CAFE_ERR_DEVICE;
+    if (rc == CAFE_OK && launch_bd_matrix_build(pool, d_sp, count, nullptr) != hipSuccess) rc = CAFE_ERR_DEVICE;
+    if (rc == CAFE_OK && hipDeviceSynchronize() != hipSuccess) rc = CAFE_ERR_DEVICE;
+    for (int i = 0; i < count && rc == CAFE_OK; ++i)
+        if (hipMemcpy2D(out + (size_t)i * n * n, (size_t)n * sizeof(double), pool.base + (int64_t)i * pool.stride,
+                        (size_t)pool.ld * sizeof(double), (size_t)n * sizeof(double), n, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = CAFE_ERR_DEVICE;
+    hipFree(pool.base);
+    hipFree(d_sp);
+    return rc;
+}
+
+int cafe_probe_fp64_mfma(int32_t device, double* tflops) {
+    if (!tflops) return CAFE_ERR_ARGUMENT;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return CAFE_ERR_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return CAFE_ERR_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return CAFE_ERR_DEVICE;
+    const int blocks = prop.multiProcessorCount * 2, iters = 20000;
+    double* d = nullptr;
+    if (hipMalloc(&d, sizeof(double) * 256 * blocks) != hipSuccess) return CAFE_ERR_MEMORY;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    (void)launch_mfma_probe(d, 200, blocks, nullptr);      // warm-up
+    (void)hipEventRecord(a, nullptr);
+    (void)launch_mfma_probe(d, iters, blocks, nullptr);
+    (void)hipEventRecord(b, nullptr);
+    int rc = hipEventSynchronize(b) == hipSuccess ? CAFE_OK : CAFE_ERR_DEVICE;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    // each wave issues iters * 8 MFMAs of 16*16*4*2 flops
+    const double flops = (double)blocks * 4 /*waves*/ * iters * 8.0 * 2048.0;
+    *tflops = ms > 0 ? flops / (ms * 1e-3) / 1e12 : 0.0;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    (void)hipFree(d);
+    return rc;
+}
+
+}  // extern "C"

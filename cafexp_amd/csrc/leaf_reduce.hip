@@ -1,0 +1,171 @@
+// K3 leaf_gather and K4 root_reduce (+ the final -lnL sum).
+//
+// K3 replaces the leaf branch of compute_node_probability (src/probability.cpp:179-199) together
+// with the mat-vec the reference then runs on the leaf's one-hot vector (src/matrix_cache.cpp:28):
+// P . e_x is column x of P, so a leaf child contributes factor[s][f] = P_leaf[s][x_f], or with an
+// error model sum_i err[x_f][i] * P_leaf[s][x_f - (n_dev-1)/2 + i] (taps outside [0,M] dropped).
+// The product over a node's leaf children is written (or multiplied) into the parent panel.
+// Bound: L2/HBM traffic (one 8-byte gather per tap and one 8-byte store per panel element).
+//
+// K4 replaces the per-family tail of base_model::infer_family_likelihoods (src/base_model.cpp:89-106)
+// and gamma_model::prune / infer_family_likelihoods (src/gamma_core.cpp:144-166, 201-225).
+#include "cafe_kernels.h"
+
+namespace cafe {
+
+constexpr int kGatherRows = 16;   // rows of the panel per block
+
+__global__ __launch_bounds__(256) void leaf_gather_kernel(const GatherArgs a) {
+    const int cat = blockIdx.z;
+    const int f = blockIdx.x * 256 + threadIdx.x;           // column inside the chunk (ld is a multiple of 128)
+    if (f >= a.ld) return;
+    const int r0 = blockIdx.y * kGatherRows;
+    double* __restrict__ dst = a.dst + (int64_t)cat * a.panel_kstride + f;
+    const int ldp = a.pool.ld;
+
+    int x[kMaxLeafPerOp];
+    const double* P[kMaxLeafPerOp];
+#pragma unroll
+    for (int l = 0; l < kMaxLeafPerOp; ++l) {
+        if (l < a.n_leaf) {
+            x[l] = a.counts[(int64_t)a.taxon[l] * a.counts_ld + a.f0 + f];
+            P[l] = a.pool.base + (int64_t)a.slot[l][cat] * a.pool.stride;
+        } else {
+            x[l] = 0;
+            P[l] = a.pool.base;
+        }
+    }
+    const int half = (a.n_dev - 1) / 2;
+
+    for (int rr = 0; rr < kGatherRows; ++rr) {
+        const int r = r0 + rr;
+        if (r >= a.rows_store) break;
+        double v = 0.0;
+        if (r < a.rows) {
+            const int64_t srow = (int64_t)(r + a.row_off) * ldp;
+            v = 1.0;
+#pragma unroll
+            for (int l = 0; l < kMaxLeafPerOp; ++l) {
+                if (l < a.n_leaf) {
+                    double fac;
+                    if (a.err == nullptr) {
+                        fac = P[l][srow + x[l]];
+                    } else {
+                        fac = 0.0;
+                        for (int i = 0; i < a.n_dev; ++i) {
+                            const int c = x[l] - half + i;
+                            if (c < 0 || c > a.max_family_size) continue;
+                            fac += P[l][srow + c] * a.err[(int64_t)x[l] * a.n_dev + i];
+                        }
+                    }
+                    v *= fac;
+                }
+            }
+            if (a.mode) v *= dst[(int64_t)r * a.ld];
+        }
+        dst[(int64_t)r * a.ld] = v;
+    }
+}
+
+hipError_t launch_leaf_gather(const GatherArgs& a, int n_categories, hipStream_t stream) {
+    dim3 grid((a.ld + 255) / 256, (a.rows_store + kGatherRows - 1) / kGatherRows, n_categories), block(256);
+    hipLaunchKernelGGL(leaf_gather_kernel, grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+
+// One thread per family; rows of the root panel are read coalesced along the family axis.
+__global__ __launch_bounds__(256) void root_reduce_kernel(const ReduceArgs a) {
+    const int64_t fl = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (fl >= a.nf) return;
+    const int64_t f = a.f0 + fl;
+    if (a.model == 0) {
+        // lnL_f = max_j( log L_j + log prior_j ), first maximum like std::max_element (base_model.cpp:94-101)
+        const double* col = a.root + fl;
+        double best = 0.0;
+        for (int j = 0; j < a.R; ++j) {
+            const double full = log(col[(int64_t)j * a.ld]) + a.log_prior[j];
+            if (j == 0 || full > best) best = full;
+        }
+        a.fam_out[f] = best;
+        a.failed[f] = 0;
+        return;
+    }
+    double lik = 0.0;
+    int fail = 0;
+    for (int k = 0; k < a.K; ++k) {
+        const double* col = a.root + (int64_t)k * a.panel_kstride + fl;
+        double sum = 0.0, best = 0.0;
+        for (int j = 0; j < a.R; ++j) {
+            const double L = col[(int64_t)j * a.ld];
+            sum += L;
+            const double full = L * a.prior[j];
+            if (j == 0 || full > best) best = full;
+        }
+        if (sum == 0.0) fail = 1;                          // "saturation", gamma_core.cpp:152
+        const double cl = best * a.cat_probs[k];            // gamma_core.cpp:162
+        a.cat_out[f * a.K + k] = cl;
+        lik += cl;                                          // gamma_core.cpp:207
+    }
+    a.fam_lik[f] = lik;
+    a.fam_out[f] = log(lik);
+    a.failed[f] = fail;
+}
+
+hipError_t launch_root_reduce(const ReduceArgs& a, hipStream_t stream) {
+    if (a.nf <= 0) return hipSuccess;
+    dim3 grid((unsigned)((a.nf + 255) / 256)), block(256);
+    hipLaunchKernelGGL(root_reduce_kernel, grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+
+// Deterministic two-stage sum: fixed block partials, then one block folds them in index order.
+__device__ inline double block_sum(double v, double* sh) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(256) void partial_sum_kernel(const double* __restrict__ fam_out, const double* __restrict__ w,
+                                                          const int32_t* __restrict__ failed, int64_t n, double* scratch) {
+    __shared__ double sh[4];
+    double s = 0.0, bad = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        s += w[i] * fam_out[i];
+        bad += failed[i] ? w[i] : 0.0;
+    }
+    const double ts = block_sum(s, sh);
+    const double tb = block_sum(bad, sh);
+    if (threadIdx.x == 0) {
+        scratch[2 * blockIdx.x] = ts;
+        scratch[2 * blockIdx.x + 1] = tb;
+    }
+}
+
+__global__ __launch_bounds__(64) void fold_sum_kernel(const double* __restrict__ scratch, int n, double* out) {
+    if (threadIdx.x != 0) return;
+    double s = 0.0, b = 0.0;
+    for (int i = 0; i < n; ++i) {
+        s += scratch[2 * i];
+        b += scratch[2 * i + 1];
+    }
+    out[0] = s;
+    out[1] = b;
+}
+
+hipError_t launch_final_sum(const double* fam_out, const double* weights, const int32_t* failed, int64_t n,
+                            double* scratch, int n_scratch, double* out, hipStream_t stream) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > n_scratch) blocks = n_scratch;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(partial_sum_kernel, dim3(blocks), dim3(256), 0, stream, fam_out, weights, failed, n, scratch);
+    hipLaunchKernelGGL(fold_sum_kernel, dim3(1), dim3(64), 0, stream, scratch, blocks, out);
+    return hipGetLastError();
+}
+
+}  // namespace cafe

@@ -1,0 +1,164 @@
+/* cafe_mi355x.h -- C ABI of the MI355X-native birth-death likelihood path.
+ *
+ * Drop-in boundary for ONE path of CAFE5 (Han9527/CAFExp): what a scorer call evaluates,
+ *   optimizer_scorer::calculate_score            src/optimizer_scorer.cpp:19
+ *     -> model::infer_family_likelihoods         src/core.h:171
+ *          base_model::infer_family_likelihoods  src/base_model.cpp:53
+ *          gamma_model::infer_family_likelihoods src/gamma_core.cpp:169
+ * i.e. matrix_cache::precalculate_matrices (src/matrix_cache.cpp:121), inference_prune
+ * (src/core.cpp:133) for every family (and gamma category) and the per-family root reduction.
+ * Everything behind this header is hand-written HIP for gfx950; there is no CPU fallback:
+ * every entry point fails (non-zero code / NULL + message) when no HIP device is usable.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every pointer it passes and nothing is
+ *     retained after a call returns except what cafe_create copies;
+ *   - numeric rejection is a VALUE, not an error: cafe_score returns 0 and writes +inf exactly
+ *     where the reference returns -log(0) (invalid lambda base_model.cpp:56-60; !can_infer
+ *     gamma_core.cpp:175-179; a zero-likelihood category gamma_core.cpp:227-236).  NaN is passed
+ *     through; the scorer maps it to +inf (optimizer_scorer.cpp:30);
+ *   - structural errors (bad arguments, HIP failures) return a non-zero code; the text is
+ *     available from cafe_last_error.  Nothing throws across this boundary;
+ *   - one call in flight per context (the reference's scorer calls are sequential).
+ *
+ * The reference-side binding a maintainer would add is shown in INTEGRATION.md; the C++ classes
+ * that wrap this ABI behind the reference's model / optimizer_scorer interfaces live in
+ * cafexp_amd/host/.
+ */
+#ifndef CAFE_MI355X_H
+#define CAFE_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAFE_ABI_VERSION 1
+#define CAFE_MAX_CATEGORIES 32
+
+typedef struct cafe_ctx cafe_ctx;
+
+enum {
+    CAFE_OK = 0,
+    CAFE_ERR_ARGUMENT = 1,   /* malformed problem / params */
+    CAFE_ERR_DEVICE = 2,     /* HIP runtime error or no usable device */
+    CAFE_ERR_MEMORY = 3,     /* problem does not fit the device */
+    CAFE_ERR_STATE = 4       /* call not valid in the context's state */
+};
+
+/* Static part of a scorer's state: replaces what model's constructor captures
+ * (src/core.cpp:58-70: tree, families, max sizes, error-model shape) plus the clade
+ * traversals the reference redoes per family (clade.cpp:255, gene_family.cpp:36). */
+typedef struct cafe_problem {
+    int32_t n_nodes;                 /* tree nodes; any order with children before parents; exactly one root */
+    const int32_t* parent;           /* [n_nodes] parent index, -1 for the root */
+    const double*  branch_length;    /* [n_nodes] clade::get_branch_length(); the root's entry is ignored */
+    const int32_t* lambda_index;     /* [n_nodes] 0-based lambda of the branch above the node
+                                        (clade::get_lambda_index_map, clade.cpp:154); NULL = all 0 */
+    const int32_t* leaf_taxon;       /* [n_nodes] column of `counts` for a leaf, -1 for interior nodes */
+    int32_t  n_taxa;
+    int64_t  n_families;
+    const int32_t* counts;           /* [n_families][n_taxa] gene_family::get_species_size */
+    int32_t  max_family_size;        /* M, user_data.cpp:46 */
+    int32_t  max_root_family_size;   /* R, user_data.cpp:45 */
+    int32_t  n_lambdas;              /* lambda::count() */
+    int32_t  single_lambda;          /* 1: single_lambda::is_valid (lambda > 0, lambda.h:58);
+                                        0: multiple_lambda::is_valid (none < 0, lambda.cpp:59) */
+    int32_t  max_categories;         /* largest K any call will use (1 for the base model) */
+    int32_t  n_deviations;           /* error_model::n_deviations(), 0 when no error model */
+    int32_t  device;                 /* HIP device ordinal */
+    int32_t  flags;                  /* CAFE_FLAG_* */
+    size_t   workspace_limit;        /* bytes of HBM the likelihood panels may take; 0 = automatic */
+} cafe_problem;
+
+#define CAFE_FLAG_NO_DEDUP 1         /* keep identical families separate (build_reference_list, base_model.cpp:27,
+                                        collapses them; values are identical either way) */
+
+enum { CAFE_MODEL_BASE = 0, CAFE_MODEL_GAMMA = 1 };
+
+/* Per scorer call: what prepare_calculation (optimizer_scorer.cpp:54,80,123,161) mutates. */
+typedef struct cafe_params {
+    int32_t model;                   /* CAFE_MODEL_BASE | CAFE_MODEL_GAMMA */
+    const double* lambdas;           /* [n_lambdas] */
+    int32_t n_categories;            /* K (gamma); ignored for the base model */
+    const double* multipliers;       /* [K] gamma_model::_lambda_multipliers */
+    const double* cat_probs;         /* [K] gamma_model::_gamma_cat_probs */
+    double  alpha;                   /* gamma shape, only for can_infer's alpha >= 0 test (gamma_core.cpp:128) */
+    const float*  prior;             /* [R] root_equilibrium_distribution::compute(j): a FLOAT in the reference */
+    const double* error_model;       /* [(M+1)][n_deviations] error_model::get_probs(x), or NULL */
+} cafe_params;
+
+/* Optional per-family outputs (host pointers, any may be NULL).
+ *   base : family_lnl[f] = max_j(log L_j + log prior_j)      (results[i], base_model.cpp:105)
+ *   gamma: category_likelihood[f*K+k] = max_j(L_j prior_j) p_k, family_likelihood[f] = sum_k
+ *          (family_info_stash rows, gamma_core.cpp:212-216); failed[f] = 1 where a category's
+ *          root vector summed to exactly 0 (gamma_core.cpp:152). */
+typedef struct cafe_family_out {
+    double*  family_lnl;
+    double*  category_likelihood;
+    double*  family_likelihood;
+    int32_t* failed;
+} cafe_family_out;
+
+/* HIP-event timings and work counters of the last cafe_score (measurement). */
+typedef struct cafe_stats {
+    double ms_total;                 /* whole call, host wall */
+    double ms_matrices;              /* K1 bd_matrix_build */
+    double ms_prune;                 /* K2 prune_gemm + K3 leaf_gather over all nodes */
+    double ms_gemm;                  /* K2 only */
+    double ms_reduce;                /* K4 root_reduce */
+    double gemm_flops;               /* algorithmic flops: sum over launches of 2*rows*(M+1)*columns */
+    double gemm_bytes;               /* algorithmic bytes of the same launches (P + B read, C written) */
+    int64_t gemm_launches;
+    int64_t n_matrices;              /* distinct (lambda_q, t_q) keys built */
+    int64_t n_unique_families;
+    int64_t n_chunks;
+    int64_t matrix_bytes;
+    int64_t panel_bytes;
+} cafe_stats;
+
+/* NULL on failure; err (optional, errlen bytes) receives the reason. */
+cafe_ctx* cafe_create(const cafe_problem* problem, char* err, size_t errlen);
+void      cafe_destroy(cafe_ctx* ctx);
+const char* cafe_last_error(const cafe_ctx* ctx);
+int       cafe_abi_version(void);
+
+/* One model::infer_family_likelihoods call: writes -lnL (or +inf / NaN, see conventions). */
+int cafe_score(cafe_ctx* ctx, const cafe_params* params, double* neg_lnl, const cafe_family_out* out);
+
+/* The same work for a family shard, without the final host read-back: device_partial must point
+ * to 2 doubles of DEVICE memory and receives {sum_f lnL_f, number of rejected/invalid families}
+ * (+inf rejection that the host can decide alone is encoded as partial[1] = 1).  The kernels are
+ * enqueued on `hip_stream` (a hipStream_t, NULL = the context's own stream) and the call returns
+ * without synchronising, so that the caller can all-reduce the pair across ranks (RCCL) on the
+ * same stream: SURVEY.md 8e. */
+int cafe_score_partial(cafe_ctx* ctx, const cafe_params* params, double* device_partial, void* hip_stream);
+/* Turns the all-reduced pair into the scorer value: +inf if partial[1] > 0 else -partial[0]. */
+double cafe_finish_partial(const double host_partial[2]);
+
+/* Per-family results of the last call (valid after the stream was synchronised). */
+int cafe_family_results(cafe_ctx* ctx, const cafe_family_out* out);
+
+/* Introspection for parity tests: the transition matrix the last call built for the branch above
+ * `node` in category k (N x N row-major, N = max(M,R)+1: matrix_cache::get_matrix), and the root
+ * likelihood vector (R values: inference_prune's return) of family f in category k. */
+int cafe_get_matrix(cafe_ctx* ctx, int32_t node, int32_t category, double* out, size_t out_len);
+int cafe_get_root_likelihoods(cafe_ctx* ctx, int64_t family, int32_t category, double* out, size_t out_len);
+int cafe_get_stats(const cafe_ctx* ctx, cafe_stats* stats);
+int cafe_matrix_size(const cafe_ctx* ctx);
+/* 1 (default): bracket every K2 launch with HIP events so that cafe_stats.ms_gemm is measured; 0: off. */
+int cafe_set_profiling(cafe_ctx* ctx, int on);
+
+/* Stand-alone kernels exposed for unit parity tests and the roofline probe. */
+/* builds `count` matrices of order n (row-major, out[count][n][n]) for (lambda[i], t[i]) pairs
+ * with matrix_cache_key quantization applied (matrix_cache.h:42-61). */
+int cafe_build_matrices(int32_t device, int32_t n, int32_t count, const double* lambdas, const double* ts, double* out);
+/* back-to-back v_mfma_f64_16x16x4_f64 issue-rate probe: returns achieved TFLOP/s on `device`. */
+int cafe_probe_fp64_mfma(int32_t device, double* tflops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
