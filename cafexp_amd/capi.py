@@ -77,6 +77,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch wheels bundle their own libamdhip64.so.7; two HIP runtimes in one process cannot both own
+    # the GPU.  Importing torch first makes this library bind to the runtime torch already loaded
+    # (same SONAME), so torch tensors / streams / torch.distributed (RCCL) and these kernels share it.
+    if os.environ.get("CAFE_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise CafeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)" % LIB_PATH)
     L = C.CDLL(LIB_PATH)

@@ -109,6 +109,7 @@ hipError_t launch_bd_matrix_build(const MatrixPool& pool, const SlotParam* d_slo
     dim3 grid(n_slots), block(64);
 #define CAFE_BD_CASE(EV)                                                                              \
     if (pool.ld <= 64 * EV) {                                                                         \
+        (void)hipGetLastError();                                                                      \
         hipLaunchKernelGGL(bd_matrix_build_kernel<EV>, grid, block, 0, stream, pool, d_slots, n_slots); \
         return hipGetLastError();                                                                     \
     }

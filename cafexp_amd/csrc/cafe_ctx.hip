@@ -62,6 +62,7 @@ struct cafe_ctx {
     int n_panels = 0, root_panel = -1;
 
     // device state
+    bool device_ready = false;
     hipStream_t stream = nullptr;
     hipStream_t last_stream = nullptr;       // stream the last call was enqueued on
     int32_t* d_counts = nullptr;
@@ -189,6 +190,7 @@ inline void quantize(double lambda, double t, long* lq, long* tq) {
 }
 
 void free_device(cafe_ctx* c) {
+    if (!c->device_ready) return;            // nothing was created on a device (argument / device errors)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     hipFree(c->d_counts); hipFree(c->d_weights); hipFree(c->pool.base); hipFree(c->d_slots); hipFree(c->d_panels);
@@ -293,6 +295,7 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_err(c, "cafe_create: no HIP device available (this library has no CPU path)"); return CAFE_ERR_DEVICE; }
     if (c->device < 0 || c->device >= ndev) { set_err(c, "cafe_create: device %d out of range (%d devices)", c->device, ndev); return CAFE_ERR_DEVICE; }
     HIP_TRY(c, hipSetDevice(c->device));
+    c->device_ready = true;
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 
     // counts, taxon-major, padded families replicate an all-zero family

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void leaf_gather_kernel(const GatherArgs a) {
 
 hipError_t launch_leaf_gather(const GatherArgs& a, int n_categories, hipStream_t stream) {
     dim3 grid((a.ld + 255) / 256, (a.rows_store + kGatherRows - 1) / kGatherRows, n_categories), block(256);
+    (void)hipGetLastError();
     hipLaunchKernelGGL(leaf_gather_kernel, grid, block, 0, stream, a);
     return hipGetLastError();
 }
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(256) void root_reduce_kernel(const ReduceArgs a) {
 hipError_t launch_root_reduce(const ReduceArgs& a, hipStream_t stream) {
     if (a.nf <= 0) return hipSuccess;
     dim3 grid((unsigned)((a.nf + 255) / 256)), block(256);
+    (void)hipGetLastError();
     hipLaunchKernelGGL(root_reduce_kernel, grid, block, 0, stream, a);
     return hipGetLastError();
 }
@@ -163,7 +165,9 @@ hipError_t launch_final_sum(const double* fam_out, const double* weights, const 
     int blocks = (int)((n + 255) / 256);
     if (blocks > n_scratch) blocks = n_scratch;
     if (blocks < 1) blocks = 1;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(partial_sum_kernel, dim3(blocks), dim3(256), 0, stream, fam_out, weights, failed, n, scratch);
+    (void)hipGetLastError();
     hipLaunchKernelGGL(fold_sum_kernel, dim3(1), dim3(64), 0, stream, scratch, blocks, out);
     return hipGetLastError();
 }

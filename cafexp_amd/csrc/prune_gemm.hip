@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
 
 hipError_t launch_prune_gemm(const GemmArgs& a, int n_categories, hipStream_t stream) {
     dim3 grid(a.n_row_tiles * a.n_col_tiles, 1, n_categories), block(256);
+    (void)hipGetLastError();
     hipLaunchKernelGGL(prune_gemm_kernel, grid, block, 0, stream, a);
     return hipGetLastError();
 }
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(double* out, int iters)
 }
 
 hipError_t launch_mfma_probe(double* d_out, int iters, int blocks, hipStream_t stream) {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, stream, d_out, iters);
     return hipGetLastError();
 }

@@ -28,7 +28,23 @@ int orc_num_threads(void) {
  * i < 1024 and ln C(n,r) for n,r < 100; both caches hold exactly what libm's lgamma
  * returns for the same integer argument, so calling lgamma() directly is value-identical.
  * --------------------------------------------------------------------------------- */
+#define LGAMMA_TABLE 8192
+static double lgamma_table[LGAMMA_TABLE];
+static int lgamma_table_ready = 0;
+static void lgamma_table_init(void) {             /* init_lgamma_cache, probability.cpp:66 */
+#pragma omp critical(orc_lgamma_init)
+    {
+        if (!lgamma_table_ready) {
+            for (int i = 0; i < LGAMMA_TABLE; ++i) { int sign; lgamma_table[i] = lgamma_r((double)i, &sign); }
+            lgamma_table_ready = 1;
+        }
+    }
+}
 static double lgamma_int(double n) {
+    if (n >= 0 && n < LGAMMA_TABLE && n == (double)(int)n) {
+        if (!lgamma_table_ready) lgamma_table_init();
+        return lgamma_table[(int)n];
+    }
     int sign;
     return lgamma_r(n, &sign);
 }
@@ -56,9 +72,9 @@ double orc_bd_log_alpha(int s, int c, double log_alpha, double coeff) {
     return lo > 0.0 ? lo : 0.0;
 }
 
-/* probability.cpp:147-164 + matrix_cache.cpp:70-77 (parent size 0 is absorbing) */
+/* probability.cpp:147-164.  (Parent size 0 is special-cased one level up, in
+ * matrix_cache::get_from_parent_fam_size_to_c, matrix_cache.cpp:70-77: see build_rows_direct.) */
 double orc_bd_prob(double lambda, double t, int s, int c) {
-    if (s == 0) return c == 0 ? 1.0 : 0.0;
     double alpha = lambda * t / (1 + lambda * t);
     double coeff = 1 - 2 * alpha;
     double result = 0;
@@ -420,7 +436,22 @@ static int distinct_branch_lengths(const orc_tree* tr, double* ts) {   /* clade.
     return nt;
 }
 
+static double g_t_matrices = 0.0, g_t_total = 0.0;
+static double now_s(void) {
+    struct timespec a;
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    return a.tv_sec + 1e-9 * a.tv_nsec;
+}
+void orc_last_timings(double* matrices_s, double* total_s) { *matrices_s = g_t_matrices; *total_s = g_t_total; }
+
+static int build_all_impl(const orc_problem* pb, const orc_params* pr, const double* mults, int K, mat_cache* cache);
 static int build_all(const orc_problem* pb, const orc_params* pr, const double* mults, int K, mat_cache* cache) {
+    double t0 = now_s();
+    int rc = build_all_impl(pb, pr, mults, K, cache);
+    g_t_matrices = now_s() - t0;
+    return rc;
+}
+static int build_all_impl(const orc_problem* pb, const orc_params* pr, const double* mults, int K, mat_cache* cache) {
     const orc_tree* tr = &pb->tree;
     int M = pb->max_family_size, R = pb->max_root_family_size;
     cache_init(cache, (M > R ? M : R) + 1);            /* base_model.cpp:77 */
@@ -457,6 +488,7 @@ static int lambdas_valid(const orc_problem* pb, const orc_params* pr) {
 /* base_model.cpp:53-112.  Identical families are pruned once in the reference
  * (build_reference_list, base_model.cpp:27); the value per family is the same either way. */
 double orc_score_base(const orc_problem* pb, const orc_params* pr, double* family_lnl) {
+    double t_start = now_s();
     if (!lambdas_valid(pb, pr)) return -log(0.0);
     mat_cache cache;
     double one = 1.0;
@@ -493,12 +525,14 @@ double orc_score_base(const orc_problem* pb, const orc_params* pr, double* famil
     if (family_lnl) memcpy(family_lnl, lnl, sizeof(double) * (size_t)F);
     free(lnl);
     cache_free(&cache);
+    g_t_total = now_s() - t_start;
     if (failed) return NAN;
     return -total;
 }
 
 /* gamma_core.cpp:123-246 */
 double orc_score_gamma(const orc_problem* pb, const orc_params* pr, double* cat_lik, double* fam_lik) {
+    double t_start = now_s();
     int K = pr->n_categories;
     const orc_tree* tr = &pb->tree;
     /* can_infer, gamma_core.cpp:123-142 (alpha >= 0 is checked by the caller that owns alpha) */
@@ -564,6 +598,7 @@ double orc_score_gamma(const orc_problem* pb, const orc_params* pr, double* cat_
     for (int64_t f = 0; f < F; ++f) total += loglik[f];
     free(loglik); free(failure);
     cache_free(&cache);
+    g_t_total = now_s() - t_start;
     if (broken) return NAN;
     if (any_fail) return -log(0.0);                       /* gamma_core.cpp:227-236 */
     return -total;

@@ -82,6 +82,7 @@ def lib():
         L.orc_time_matrices.restype = C.c_double
         L.orc_time_matrices.argtypes = [C.c_int, C.c_double, _f64p, C.c_int, C.c_int]
         L.orc_num_threads.restype = C.c_int
+        L.orc_last_timings.argtypes = [_f64p, _f64p]
         _lib = L
     return _lib
 
@@ -214,6 +215,12 @@ def score(pb, pr, fast: bool = False):
 def time_matrices(n: int, lam: float, ts, fast: bool = False) -> float:
     ts = np.ascontiguousarray(ts, dtype=np.float64)
     return lib().orc_time_matrices(n, lam, _p(ts, _f64p), len(ts), 1 if fast else 0)
+
+
+def last_timings():
+    a, b = C.c_double(), C.c_double()
+    lib().orc_last_timings(C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 def num_threads() -> int:

@@ -1,0 +1,324 @@
+"""GPU parity tests proper: everything goes through the C ABI (libcafe_mi355x.so) on a real MI355X and
+is compared with the CPU oracle / the golden vectors of the compiled reference.
+
+Tolerances: the hot path is fp64 end to end; BASELINE.json asks for -lnL within 1e-6 relative.  We hold
+the kernels to SCORE_TOL = 1e-10 on -lnL and VEC_TOL = 5e-11 on likelihood vectors/matrix entries
+(measured: ~1e-13; sources of difference: O(N^2) matrix recurrence vs the reference's log-space sum,
+MFMA summation order, device log())."""
+import dataclasses
+import math
+
+import numpy as np
+import pytest
+
+from cafexp_amd import problem as P
+from helpers import case_from_args, rel_err
+
+pytestmark = pytest.mark.gpu
+
+SCORE_TOL = 1e-10
+VEC_TOL = 5e-11
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from cafexp_amd import capi as C
+    C.load()
+    return C
+
+
+def _ab_problem(newick, counts, M, R, **kw):
+    tree = P.parse_newick(newick)
+    species = sorted(counts[0].keys())
+    table = np.array([[fam[s] for s in species] for fam in counts], dtype=np.int32)
+    return P.build_problem(tree, species, ["f%d" % i for i in range(len(counts))], table, root_filter=False,
+                           max_family_size=M, max_root_family_size=R, **kw)
+
+
+# ------------------------------------------------------------------ K1
+@pytest.mark.parametrize("n,lam,t", [(5, 0.05, 5.0), (141, 0.006335, 68.7105), (141, 0.006335, 68.0), (141, 0.01, 96.435575),
+                                     (10, 0.05, 25.0), (12, 0.02, 25.0), (21, 0.045, 3.0), (64, 0.002, 0.0004), (300, 0.003, 40.0),
+                                     (17, 0.5, 1.0), (130, 1e-5, 0.01), (751, 0.0053, 53.667)])
+def test_matrix_build_vs_oracle(capi, oracle, n, lam, t):
+    got = capi.build_matrices(n, [lam], [t])[0]
+    want = oracle.build_matrix(n, lam, t, fast=(n > 400))      # the O(N^3) oracle build at 751 takes minutes; conv is pinned to it at smaller n
+    assert np.array_equal(got[0], want[0])                      # row 0 = e_0
+    if not want[1:].any():                                      # saturated / degenerate / t_q = 0: rows s >= 1 are exactly 0
+        assert not got[1:].any()
+    big = want > 1e-290
+    assert (np.abs(got - want)[big] / want[big]).max(initial=0.0) <= VEC_TOL
+    # deep-underflow entries (alpha^k below ~1e-290) may flush to 0 at different k in the two algorithms
+    assert got[~big].max(initial=0.0) <= 1e-280 and want[got <= 1e-290].max(initial=0.0) <= 1e-280
+    assert got.min() >= 0.0 and got.max() <= 1.0
+
+
+def test_matrix_build_golden(capi, golden):
+    for e in golden["matrices"]:
+        got = capi.build_matrices(e["n"], [e["lambda"]], [e["t"]])[0]
+        exp = np.array(e["diag"])
+        big = exp > 1e-290
+        assert (np.abs(got.diagonal() - exp)[big] / exp[big]).max(initial=0.0) <= VEC_TOL
+        if "full" in e:
+            exp = np.array(e["full"])
+            assert np.array_equal(got == 0, exp == 0)
+            assert (np.abs(got - exp) / np.maximum(exp, 1e-300)).max() <= VEC_TOL
+
+
+def test_matrix_batch_and_key_collisions(capi, oracle):
+    lam = [0.01, 0.01, 0.002, 0.002]
+    ts = [68.710507, 68.7105, 1.001, 1.0]                     # pairs that quantize to the same key
+    got = capi.build_matrices(33, lam, ts)
+    assert np.array_equal(got[0], got[1]) and np.array_equal(got[2], got[3])
+    assert np.abs(got[2] - oracle.build_matrix(33, 0.002, 1.0)).max() <= VEC_TOL
+
+
+# ------------------------------------------------------------------ reference known answers through the C ABI
+def test_infer_processes(capi):                                 # test.cpp:519 -> 41.7504
+    pb = _ab_problem("(A:1,B:1);", [{"A": 1, "B": 2}, {"A": 2, "B": 1}, {"A": 3, "B": 6}, {"A": 6, "B": 3}], 56, 30)
+    ctx = capi.Context(pb)
+    v = ctx.score(P.Params(lambdas=np.array([0.01]), prior=P.prior_uniform(30)))
+    assert v == pytest.approx(41.7504, abs=1e-3)
+    assert rel_err(v, 41.75042830803) <= 1e-11
+
+
+def test_gamma_lambda_optimizer_value(capi, oracle):            # test.cpp:2240 -> 6.4168
+    pb = _ab_problem("(A:1,B:1);", [{"A": 1, "B": 2}], 10, 10)
+    probs, mult = oracle.discrete_gamma(4, 0.25)
+    ctx = capi.Context(pb, max_categories=4)
+    v = ctx.score(P.Params(lambdas=np.array([0.01]), prior=P.prior_uniform(10), multipliers=mult, cat_probs=probs), alpha=0.25)
+    assert v == pytest.approx(6.4168, abs=1e-4)
+    assert rel_err(v, 6.4168193056853) <= 1e-11
+
+
+def test_prune_root_vectors_golden(capi, golden):               # test.cpp:1642 / :1709 / :1745 inputs, reference outputs
+    from helpers import read
+    for e in golden["prune"]:
+        counts = dict((kv.split(":")[0], int(kv.split(":")[1])) for kv in e["counts"].split(","))
+        pb = _ab_problem(e["newick"], [counts], e["m"], e["r"])
+        pr = P.Params(lambdas=np.array([e["lambda"]]), prior=P.prior_uniform(e["r"]),
+                      multipliers=np.array([e["mult"]]), cat_probs=np.array([1.0]))
+        if "errfile" in e:
+            _, dev, dists = P.read_error_model(read(e["errfile"]))
+            pb.n_deviations = len(dev)
+            pr.error_model = P.error_model_table(dists, e["m"])
+        ctx = capi.Context(pb, max_categories=1)
+        ctx.score(pr)
+        got = ctx.root_likelihoods(0, 0)
+        exp = np.array(e["root"])
+        assert np.array_equal(got == 0, exp == 0)
+        assert (np.abs(got - exp) / np.maximum(exp, 1e-300)).max() <= VEC_TOL, e["newick"]
+
+
+def test_gamma_model_prune_category_likelihoods(capi):          # test.cpp:1224: -23.3728, -17.0086
+    pb = _ab_problem("(A:1,B:3):7", [{"A": 3, "B": 6}], 10, 8)
+    rd = [1, 2, 3, 4, 5, 4, 3, 2, 1]
+    prior = np.array([np.float32(rd[j]) / np.float32(sum(rd)) for j in range(8)], dtype=np.float32)
+    pr = P.Params(lambdas=np.array([0.005]), prior=prior, multipliers=np.array([0.1, 0.5]), cat_probs=np.array([0.01, 0.05]))
+    ctx = capi.Context(pb, max_categories=2)
+    v, res = ctx.score(pr, per_family=True)
+    assert math.log(res["category_likelihood"][0, 0]) == pytest.approx(-23.3728, abs=1e-4)
+    assert math.log(res["category_likelihood"][0, 1]) == pytest.approx(-17.0086, abs=1e-4)
+
+
+def test_gamma_model_prune_returns_false_if_saturated(capi):    # test.cpp:1250: lambda 0.9 x {0.1, 0.5} on t = 1,3,7
+    pb = _ab_problem("(A:1,B:3):7", [{"A": 3, "B": 6}], 10, 8)
+    pr = P.Params(lambdas=np.array([0.9]), prior=P.prior_uniform(8), multipliers=np.array([0.1, 0.5]), cat_probs=np.array([1.0, 1.0]))
+    ctx = capi.Context(pb, max_categories=2)
+    assert ctx.score(pr) == math.inf
+
+
+# ------------------------------------------------------------------ golden scorer calls (compiled reference)
+@pytest.mark.parametrize("name", [
+    "mammals_base_l0.01", "mammals_base_l0.002", "mammals_base_nofilter", "mammals_gamma_k4_a2", "mammals_gamma_k4_a4",
+    "mammals_gamma_k4_inf", "mammals_gamma_k3_a0.425", "mammals_multilambda", "mammals_multilambda_err", "mammals_err_poisson10",
+    "mammals_rootdist", "mammals_first200_base", "mammals_first200_gamma", "mammals_first200_err", "synth20_base",
+    "synth20_gamma_k8", "synth20_multilambda_err", "synth100_base"])
+def test_golden_scores(capi, oracle, golden, name):
+    e = golden["scores"][name]
+    pb, pr, alpha = case_from_args(e["args"], oracle)
+    K = len(pr.multipliers) if pr.multipliers is not None else 1
+    ctx = capi.Context(pb, max_categories=K)
+    v = ctx.score(pr, alpha=alpha)
+    assert rel_err(v, e["neg_lnl"]) <= SCORE_TOL, (v, e["neg_lnl"])
+    if math.isinf(e["neg_lnl"]):
+        return
+    res = ctx.family_results(K if pr.multipliers is not None else 0)
+    if "family_lnl" in e:
+        assert np.abs(res["family_lnl"] / np.array(e["family_lnl"]) - 1).max() <= SCORE_TOL
+    if "category_likelihood" in e:
+        assert np.abs(res["category_likelihood"].ravel() / np.array(e["category_likelihood"]) - 1).max() <= VEC_TOL
+        assert np.abs(res["family_likelihood"] / np.array(e["family_likelihood"]).reshape(-1, K)[:, 0] - 1).max() <= VEC_TOL
+    ctx.close()
+
+
+# ------------------------------------------------------------------ rejection / error conventions
+def test_rejections_return_inf(capi, oracle):
+    pb = _ab_problem("((A:1,B:1):1,C:2);", [{"A": 1, "B": 2, "C": 1}, {"A": 0, "B": 2, "C": 3}], 20, 15)
+    ctx = capi.Context(pb, max_categories=3)
+    prior = P.prior_uniform(15)
+    assert ctx.score(P.Params(lambdas=np.array([0.0]), prior=prior)) == math.inf           # single_lambda::is_valid: lambda > 0
+    assert ctx.score(P.Params(lambdas=np.array([-0.01]), prior=prior)) == math.inf
+    probs, mult = oracle.discrete_gamma(3, 1.0)
+    g = P.Params(lambdas=np.array([0.01]), prior=prior, multipliers=mult, cat_probs=probs)
+    assert math.isfinite(ctx.score(g, alpha=1.0))
+    assert ctx.score(g, alpha=-0.5) == math.inf                                             # can_infer: alpha < 0
+    g2 = P.Params(lambdas=np.array([0.4]), prior=prior, multipliers=mult, cat_probs=probs)  # 2 * 0.4 * max mult saturates
+    assert ctx.score(g2, alpha=1.0) == math.inf == oracle.score_gamma(pb, g2)
+    with pytest.raises(capi.CafeError):
+        ctx.family_results(3)                                                                # rejected call leaves no results
+    # base model with a saturated branch is NOT rejected: zero matrix -> log(0) -> +inf naturally
+    b = P.Params(lambdas=np.array([0.6]), prior=prior)
+    assert ctx.score(b) == oracle.score_base(pb, b) == math.inf
+    # a multiple-lambda problem accepts lambda == 0 as valid (lambda.cpp:59) and then scores through zero matrices
+    lt = P.parse_newick("((A:1,B:1):1,C:2);", lambda_tree=True)
+    tree = P.parse_newick("((A:1,B:1):1,C:2);")
+    pbm = P.build_problem(tree, ["A", "B", "C"], ["x"], np.array([[1, 2, 1]], dtype=np.int32), lambda_tree=lt, root_filter=False,
+                          max_family_size=20, max_root_family_size=15)
+    ctxm = capi.Context(pbm)
+    pm = P.Params(lambdas=np.array([-1e-9]), prior=prior)
+    assert ctxm.score(pm) == math.inf
+
+
+def test_nan_passthrough(capi):
+    """A NaN prior makes the reference return NaN from infer_family_likelihoods; the scorer maps it to +inf
+    (optimizer_scorer.cpp:30).  The C ABI passes the NaN through."""
+    pb = _ab_problem("(A:1,B:1);", [{"A": 1, "B": 2}], 10, 10)
+    prior = P.prior_uniform(10)
+    prior[:] = np.nan
+    ctx = capi.Context(pb)
+    assert math.isnan(ctx.score(P.Params(lambdas=np.array([0.01]), prior=prior)))
+
+
+def test_argument_errors(capi):
+    pb = _ab_problem("(A:1,B:1);", [{"A": 1, "B": 2}], 10, 10)
+    bad = dataclasses.replace(pb, counts=np.array([[1, 50]], dtype=np.int32))                # count above M
+    with pytest.raises(capi.CafeError):
+        capi.Context(bad)
+    bad = dataclasses.replace(pb, parent=np.array([2, 2, 1], dtype=np.int32))               # parent before child
+    with pytest.raises(capi.CafeError):
+        capi.Context(bad)
+    ctx = capi.Context(pb, max_categories=2)
+    with pytest.raises(capi.CafeError):                                                      # more categories than created for
+        ctx.score(P.Params(lambdas=np.array([0.01]), prior=P.prior_uniform(10), multipliers=np.ones(3), cat_probs=np.ones(3) / 3))
+    with pytest.raises(capi.CafeError):                                                      # error model without n_deviations
+        ctx.score(P.Params(lambdas=np.array([0.01]), prior=P.prior_uniform(10), error_model=np.ones((11, 3)) / 3))
+    with pytest.raises(capi.CafeError):
+        capi.Context(pb, device=99)
+
+
+# ------------------------------------------------------------------ structure: N-ary, ragged, dedup, chunks
+def _random_problem(rng, newick, n_fam, M, R, hi):
+    tree = P.parse_newick(newick)
+    names = [l.name for l in tree.leaves()]
+    counts = rng.integers(0, hi, size=(n_fam, len(names))).astype(np.int32)
+    return P.build_problem(tree, names, ["f%d" % i for i in range(n_fam)], counts, root_filter=False,
+                           max_family_size=M, max_root_family_size=R)
+
+
+@pytest.mark.parametrize("newick", [
+    "(A:1.5,B:2.25,C:0.7);",                                     # polytomy at the root
+    "((A:1,B:1,C:2,D:0.5,E:1,F:3):2,(G:1,H:2):0.5,I:4);",        # 6 leaf children (> leaves per gather launch) + mixed
+    "((((A:1,B:1):1,C:2):1,D:3):1,E:4);",                        # caterpillar
+    "(((A:1,B:1):1,(C:1,D:1):1):1,((E:1,F:1):1,(G:1,H:1):1):1);",    # balanced
+    "((A:0.0004,B:1):1,C:2);",                                   # t_q = 0 branch: zero rows (matrix_cache.h:50)
+])
+def test_tree_shapes(capi, oracle, newick):
+    rng = np.random.default_rng(5)
+    pb = _random_problem(rng, newick, 70, 40, 30, 12)
+    probs, mult = oracle.discrete_gamma(3, 1.3)
+    ctx = capi.Context(pb, max_categories=3)
+    for pr in (P.Params(lambdas=np.array([0.02]), prior=P.prior_uniform(30)),
+               P.Params(lambdas=np.array([0.02]), prior=P.prior_poisson(30, 4.0), multipliers=mult, cat_probs=probs)):
+        got = ctx.score(pr, alpha=1.3)
+        want = oracle.score(pb, pr)
+        assert rel_err(got, want) <= SCORE_TOL, (newick, got, want)
+
+
+def test_dedup_and_weights(capi, oracle):
+    rng = np.random.default_rng(9)
+    pb = _random_problem(rng, "((A:1,B:2):1,(C:1,D:3):2);", 40, 30, 25, 3)              # tiny range -> many duplicates
+    pr = P.Params(lambdas=np.array([0.03]), prior=P.prior_uniform(25))
+    a = capi.Context(pb, dedup=True)
+    b = capi.Context(pb, dedup=False)
+    va, ra = a.score(pr, per_family=True)
+    vb, rb = b.score(pr, per_family=True)
+    assert a.stats()["n_unique_families"] < 40 == b.stats()["n_unique_families"]
+    assert rel_err(va, vb) <= 1e-13 and np.array_equal(ra["family_lnl"], rb["family_lnl"])
+    assert rel_err(va, oracle.score_base(pb, pr)) <= SCORE_TOL
+
+
+def test_chunked_workspace_equals_single_chunk(capi, oracle):
+    rng = np.random.default_rng(11)
+    pb = _random_problem(rng, "(((A:1,B:1):1,(C:1,D:1):1):1,((E:1,F:1):1,(G:1,H:1):1):1);", 700, 60, 50, 25)
+    probs, mult = oracle.discrete_gamma(2, 2.0)
+    pr = P.Params(lambdas=np.array([0.01]), prior=P.prior_uniform(50), multipliers=mult, cat_probs=probs)
+    one = capi.Context(pb, max_categories=2)
+    many = capi.Context(pb, max_categories=2, workspace_limit=3 * 2 * 64 * 8 * 256 + 1)   # room for 256 columns -> 3 chunks
+    v1, r1 = one.score(pr, alpha=2.0, per_family=True)
+    v2, r2 = many.score(pr, alpha=2.0, per_family=True)
+    assert many.stats()["n_chunks"] >= 3 and one.stats()["n_chunks"] == 1
+    assert np.array_equal(r1["family_likelihood"], r2["family_likelihood"])
+    assert rel_err(v1, v2) <= 1e-14
+    assert rel_err(v1, oracle.score_gamma(pb, pr)) <= SCORE_TOL
+
+
+def test_repeated_calls_are_stateless(capi, oracle):
+    rng = np.random.default_rng(13)
+    pb = _random_problem(rng, "((A:1,B:2):1,(C:1,D:3):2);", 130, 50, 40, 20)
+    ctx = capi.Context(pb, max_categories=4)
+    probs, mult = oracle.discrete_gamma(4, 0.9)
+    seq = [P.Params(lambdas=np.array([0.01]), prior=P.prior_uniform(40)),
+           P.Params(lambdas=np.array([0.02]), prior=P.prior_uniform(40), multipliers=mult, cat_probs=probs),
+           P.Params(lambdas=np.array([-1.0]), prior=P.prior_uniform(40)),
+           P.Params(lambdas=np.array([0.01]), prior=P.prior_uniform(40))]
+    vals = [ctx.score(p, alpha=0.9) for p in seq]
+    assert vals[0] == vals[3] and vals[2] == math.inf
+    assert rel_err(vals[1], oracle.score_gamma(pb, seq[1])) <= SCORE_TOL
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE config 4 shape)
+def test_config4_shape_properties(capi, oracle):
+    """100 taxa / max count 600 (N = 751) / K = 8 at a family count the box finishes in seconds.  The oracle
+    cannot run this size in test time, so: (i) a family subset against the oracle (O(N^2) matrices),
+    (ii) size-independent properties: shard additivity, permutation invariance, duplicate linearity."""
+    from cafexp_amd import synth
+    pb, _ = synth.make_problem(n_families=1024)
+    assert (pb.max_family_size, pb.max_root_family_size, pb.matrix_size) == (720, 750, 751)
+    probs, mult = oracle.discrete_gamma(8, 2.0)
+    pr = P.Params(lambdas=np.array([0.002]), prior=P.prior_uniform(750), multipliers=mult, cat_probs=probs)
+    ctx = capi.Context(pb, max_categories=8)
+    whole, res = ctx.score(pr, alpha=2.0, per_family=True)
+    assert math.isfinite(whole) and not res["failed"].any()
+    # (i) subset vs oracle
+    sel = np.array([0, 1, 17, 500, 1023])
+    sub = dataclasses.replace(pb, counts=pb.counts[sel].copy(), family_ids=[pb.family_ids[i] for i in sel])
+    _, cat, fam = oracle.score_gamma(sub, pr, fast=True, per_family=True)
+    assert np.abs(res["category_likelihood"][sel] / cat - 1).max() <= VEC_TOL
+    # (ii) additivity over shards (what the multi-GPU all-reduce relies on) and permutation invariance
+    parts = 0.0
+    for lo, hi in [P.shard_families(pb.n_families, 3, r) for r in range(3)]:
+        shard = dataclasses.replace(pb, counts=pb.counts[lo:hi].copy(), family_ids=pb.family_ids[lo:hi])
+        parts += capi.Context(shard, max_categories=8).score(pr, alpha=2.0)
+    assert rel_err(parts, whole) <= 1e-12
+    assert rel_err(-np.sum(np.log(res["family_likelihood"])), whole) <= 1e-12
+    perm = np.random.default_rng(1).permutation(pb.n_families)
+    shuffled = dataclasses.replace(pb, counts=pb.counts[perm].copy())
+    assert rel_err(capi.Context(shuffled, max_categories=8).score(pr, alpha=2.0), whole) <= 1e-12
+    doubled = dataclasses.replace(pb, counts=np.concatenate([pb.counts, pb.counts]), family_ids=pb.family_ids * 2)
+    assert rel_err(capi.Context(doubled, max_categories=8).score(pr, alpha=2.0), 2 * whole) <= 1e-12
+
+
+def test_partial_api_on_torch_stream(capi, oracle):
+    """cafe_score_partial leaves {sum lnL, rejects} in device memory on the caller's stream (the multi-GPU path)."""
+    import torch
+    rng = np.random.default_rng(17)
+    pb = _random_problem(rng, "((A:1,B:2):1,(C:1,D:3):2);", 300, 50, 40, 20)
+    pr = P.Params(lambdas=np.array([0.015]), prior=P.prior_uniform(40))
+    ctx = capi.Context(pb)
+    buf = torch.zeros(2, dtype=torch.float64, device="cuda:0")
+    stream = torch.cuda.current_stream()
+    ctx.score_partial(pr, buf.data_ptr(), stream.cuda_stream)
+    got = ctx.finish(buf.cpu().numpy())
+    assert rel_err(got, oracle.score_base(pb, pr)) <= SCORE_TOL
+    ctx.score_partial(P.Params(lambdas=np.array([-1.0]), prior=P.prior_uniform(40)), buf.data_ptr(), stream.cuda_stream)
+    assert ctx.finish(buf.cpu().numpy()) == math.inf
