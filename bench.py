@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--alpha", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-matrices", type=int, default=3, help="matrices built by the O(N^3) reference algorithm in the CPU sample")
-    ap.add_argument("--cpu-families", type=int, default=0, help="families pruned in the CPU sample (0 = 8 per host thread)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU sample (0 = the host CPU share)")
+    ap.add_argument("--cpu-families", type=int, default=0, help="families pruned in the CPU sample (0 = 4 per host thread)")
     return ap.parse_args()
 
 
@@ -52,13 +53,14 @@ def cpu_baseline(pb, pr, args, n_matrices_call):
     import dataclasses
     import numpy as np
     from oracle import oracle as O
-    threads = O.num_threads()
+    threads = min(O.host_cpu_share(), args.cpu_threads or 10 ** 6)
+    O.set_threads(threads)                            # OpenMP would otherwise take every logical CPU of the host
     n = pb.matrix_size
     ts = sorted({float(t) for t in pb.branch_length if t > 0})
     pick = [ts[(i * len(ts)) // args.cpu_matrices] for i in range(args.cpu_matrices)]
     t_mat = O.time_matrices(n, args.lam, pick, fast=False)
     per_matrix = t_mat / len(pick)
-    nf = args.cpu_families or 8 * threads
+    nf = args.cpu_families or 4 * threads
     nf = min(nf, pb.n_families)
     sub = dataclasses.replace(pb, counts=pb.counts[:nf].copy(), family_ids=pb.family_ids[:nf])
     O.score(sub, pr, fast=True)                       # matrices by the O(N^2) build: only the prune is timed

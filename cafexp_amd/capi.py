@@ -112,7 +112,7 @@ def load():
     L.cafe_matrix_size.restype = C.c_int
     L.cafe_matrix_size.argtypes = [C.c_void_p]
     L.cafe_build_matrices.restype = C.c_int
-    L.cafe_build_matrices.argtypes = [C.c_int32, C.c_int32, C.c_int32, _f64p, _f64p, _f64p]
+    L.cafe_build_matrices.argtypes = [C.c_int32, C.c_int32, C.c_int32, _f64p, _f64p, C.c_int32, _f64p]
     L.cafe_probe_fp64_mfma.restype = C.c_int
     L.cafe_probe_fp64_mfma.argtypes = [C.c_int32, _f64p]
     L.cafe_set_profiling.restype = C.c_int
@@ -253,11 +253,11 @@ class Context:
         self._check(self._lib.cafe_set_profiling(self._h, 1 if on else 0))
 
 
-def build_matrices(n: int, lambdas, ts, device: int = 0) -> np.ndarray:
+def build_matrices(n: int, lambdas, ts, device: int = 0, layout: int = 0) -> np.ndarray:
     lam = np.ascontiguousarray(lambdas, dtype=np.float64)
     t = np.ascontiguousarray(ts, dtype=np.float64)
     out = np.empty((len(lam), n, n))
-    rc = load().cafe_build_matrices(device, n, len(lam), _p(lam, _f64p), _p(t, _f64p), _p(out, _f64p))
+    rc = load().cafe_build_matrices(device, n, len(lam), _p(lam, _f64p), _p(t, _f64p), layout, _p(out, _f64p))
     if rc:
         raise CafeError("cafe_build_matrices failed with code %d" % rc)
     return out

@@ -16,22 +16,35 @@
 // Mapping: ONE 64-lane wave per matrix.  Lane l owns E consecutive columns of the current row
 // in registers; a row step is E local FMAs, a 6-step Kogge-Stone scan over the 64 lane
 // aggregates with the constant ratio a^E (DPP/permute shuffles, no LDS, no barrier), and E
-// fix-up FMAs.  The N-1 row steps are sequential; the grid has one wave per (branch, category)
-// matrix, so a call with hundreds of matrices fills the chip.  Bound: HBM write of the pool
-// (8*N*ld bytes per matrix), see DESIGN.md.
+// fix-up FMAs.  The row steps are sequential; the grid has one wave per (branch, category)
+// matrix, so a call with hundreds of matrices fills the chip.  Bound: HBM write of the pool.
+//
+// Two output layouts:
+//   row-major  P[s][c]              -- leaf branches: K3 reads column x of P (P . e_x)
+//   k-major    Pt[c][j] = P[j+1][c] -- interior branches: the A operand of K2, contraction index c
+//                                      outermost so that an A tile row is contiguous in LDS-DMA order.
+// The k-major layout is written without a transpose: the process is reversible with respect to
+// pi(n) = 1/n, so P[s][c] = (s/c) P[c][s] for s,c >= 1; Pt's row c is P's row c scaled by s/c
+// (one extra rounding), Pt's row 0 is P[s][0] = a^s, and P's row 0 (e_0) is never stored: K2
+// copies that row (prune_gemm.hip).
 #include "cafe_kernels.h"
 
 namespace cafe {
 
-template <int E>
+template <int E, bool KMAJOR>
 __global__ __launch_bounds__(64) void bd_matrix_build_kernel(MatrixPool pool, const SlotParam* __restrict__ slots, int n_slots) {
     const int lane = threadIdx.x;
     const int slot = blockIdx.x;
     if (slot >= n_slots) return;
     const SlotParam sp = slots[slot];
     double* __restrict__ P = pool.base + (int64_t)slot * pool.stride;
-    const int n = pool.n, ld = pool.ld;
-    const int c0 = lane * E;
+    const int ld = pool.ld;
+    const int n = pool.n;                             // matrix order N (sizes 0..N-1)
+    const int n_rows = KMAJOR ? pool.rows : n;        // rows to write
+    const int k_valid = KMAJOR ? pool.k_valid : n;    // recurrence rows that are ever read
+    constexpr int e_base = KMAJOR ? 1 : 0;            // first owned column of lane 0
+    const int c0 = e_base + lane * E;                 // owned columns c0 .. c0+E-1 of the current P row
+    const int j0 = lane * E;                          // where they are stored
     const double a = sp.alpha, q = sp.oma2;
 
     double apow[E];                      // a^(i+1)
@@ -43,46 +56,55 @@ __global__ __launch_bounds__(64) void bd_matrix_build_kernel(MatrixPool pool, co
 #pragma unroll
     for (int d = 1; d < 6; ++d) ratio[d] = ratio[d - 1] * ratio[d - 1];
 
-    double p[E];
+    double p[E];                         // P[row][c0 + i]
+    double p0 = 1.0;                     // P[row][0] = a^row (k-major only: lane 0's left neighbour)
 #pragma unroll
     for (int i = 0; i < E; ++i) p[i] = (c0 + i == 0) ? 1.0 : 0.0;
 
-    auto store_row = [&](int s) {
-        double* row = P + (int64_t)s * ld + c0;
-        if constexpr (E % 2 == 0) {
+    auto store_row = [&](int r, const double* v) {
+        double* row = P + (int64_t)r * ld + j0;
 #pragma unroll
-            for (int i = 0; i < E; i += 2) {
-                if (c0 + i < ld) {       // ld is even, c0+i is even: the pair is in or out together
-                    double2 v;
-                    v.x = (c0 + i < n) ? p[i] : 0.0;
-                    v.y = (c0 + i + 1 < n) ? p[i + 1] : 0.0;
-                    *reinterpret_cast<double2*>(row + i) = v;
-                }
+        for (int i = 0; i < E; i += 2) {
+            if (j0 + i < ld) {           // ld and j0+i are even: the pair is in or out together
+                double2 w;
+                w.x = (c0 + i < n) ? v[i] : 0.0;
+                w.y = (c0 + i + 1 < n) ? v[i + 1] : 0.0;
+                *reinterpret_cast<double2*>(row + i) = w;
             }
-        } else {
-#pragma unroll
-            for (int i = 0; i < E; ++i)
-                if (c0 + i < ld) row[i] = (c0 + i < n) ? p[i] : 0.0;
         }
     };
 
-    store_row(0);
-    if (sp.zero) {
+    double z[E];
 #pragma unroll
-        for (int i = 0; i < E; ++i) p[i] = 0.0;
-        for (int s = 1; s < n; ++s) store_row(s);
+    for (int i = 0; i < E; ++i) z[i] = 0.0;
+
+    if (sp.zero) {                       // saturated / degenerate: every entry with parent size >= 1 is 0
+        if (!KMAJOR) store_row(0, p);    // row-major keeps P's row 0 = e_0; k-major never holds it
+        for (int r = KMAJOR ? 0 : 1; r < n_rows; ++r) store_row(r, z);
         return;
     }
 
-    for (int s = 1; s < n; ++s) {
+    if (KMAJOR) {
+        double v[E];                     // Pt[0][j] = P[j+1][0] = a^(j+1)
+#pragma unroll
+        for (int i = 0; i < E; ++i) v[i] = pow(a, (double)(c0 + i));
+        store_row(0, v);
+    } else {
+        store_row(0, p);
+    }
+
+    for (int r = 1; r < n_rows; ++r) {
+        if (r >= k_valid || r >= n) {    // contraction rows past M (or past the matrix) are never read: keep them 0
+            store_row(r, z);
+            continue;
+        }
         double left = __shfl_up(p[E - 1], 1);
-        if (lane == 0) left = 0.0;
+        if (lane == 0) left = KMAJOR ? p0 : 0.0;
         double h[E];
         h[0] = left;
 #pragma unroll
         for (int i = 1; i < E; ++i) h[i] = fma(a, h[i - 1], p[i - 1]);
-        // inclusive scan of the lane totals with ratio a^E
-        double S = h[E - 1];
+        double S = h[E - 1];             // inclusive scan of the lane totals with ratio a^E
 #pragma unroll
         for (int d = 0; d < 6; ++d) {
             double up = __shfl_up(S, 1 << d);
@@ -97,21 +119,35 @@ __global__ __launch_bounds__(64) void bd_matrix_build_kernel(MatrixPool pool, co
             v = v < 1.0 ? v : 1.0;
             p[i] = v > 0.0 ? v : 0.0;
         }
-        store_row(s);
+        p0 *= a;
+        if (KMAJOR) {
+            const double inv_r = 1.0 / (double)r;
+            double v[E];
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                double t = p[i] * ((double)(c0 + i) * inv_r);     // P[s][c] = (s/c) P[c][s]
+                v[i] = t < 1.0 ? t : 1.0;
+            }
+            store_row(r, v);
+        } else {
+            store_row(r, p);
+        }
     }
 }
 
 int bd_matrix_max_order() { return 64 * 32; }
 
-hipError_t launch_bd_matrix_build(const MatrixPool& pool, const SlotParam* d_slots, int n_slots, hipStream_t stream) {
+template <bool KMAJOR>
+static hipError_t launch_layout(const MatrixPool& pool, const SlotParam* d_slots, int n_slots, hipStream_t stream) {
     if (n_slots <= 0) return hipSuccess;
-    if (pool.ld > bd_matrix_max_order() || (pool.ld & 1)) return hipErrorInvalidValue;
+    const int cols = KMAJOR ? pool.n - 1 : pool.n;      // owned columns needed: c = e_base .. n-1
+    if (cols > bd_matrix_max_order() || (pool.ld & 1)) return hipErrorInvalidValue;
     dim3 grid(n_slots), block(64);
-#define CAFE_BD_CASE(EV)                                                                              \
-    if (pool.ld <= 64 * EV) {                                                                         \
-        (void)hipGetLastError();                                                                      \
-        hipLaunchKernelGGL(bd_matrix_build_kernel<EV>, grid, block, 0, stream, pool, d_slots, n_slots); \
-        return hipGetLastError();                                                                     \
+#define CAFE_BD_CASE(EV)                                                                                          \
+    if (cols <= 64 * EV) {                                                                                        \
+        (void)hipGetLastError();                                                                                  \
+        hipLaunchKernelGGL((bd_matrix_build_kernel<EV, KMAJOR>), grid, block, 0, stream, pool, d_slots, n_slots); \
+        return hipGetLastError();                                                                                 \
     }
     CAFE_BD_CASE(2)
     CAFE_BD_CASE(4)
@@ -127,6 +163,10 @@ hipError_t launch_bd_matrix_build(const MatrixPool& pool, const SlotParam* d_slo
     CAFE_BD_CASE(32)
 #undef CAFE_BD_CASE
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_bd_matrix_build(const MatrixPool& pool, const SlotParam* d_slots, int n_slots, hipStream_t stream) {
+    return pool.kmajor ? launch_layout<true>(pool, d_slots, n_slots, stream) : launch_layout<false>(pool, d_slots, n_slots, stream);
 }
 
 }  // namespace cafe

@@ -67,9 +67,10 @@ struct cafe_ctx {
     hipStream_t last_stream = nullptr;       // stream the last call was enqueued on
     int32_t* d_counts = nullptr;
     double* d_weights = nullptr;
-    MatrixPool pool{nullptr, 0, 0, 0};
-    int max_slots = 0;
-    SlotParam* d_slots = nullptr;
+    MatrixPool pool{nullptr, 0, 0, 0, 0, 0, 0};     // row-major matrices of leaf branches (K3)
+    MatrixPool kpool{nullptr, 0, 0, 0, 0, 0, 1};    // k-major matrices of interior branches (K2)
+    int max_slots = 0, max_kslots = 0;
+    SlotParam* d_slots = nullptr;                   // [max_slots] row-major, then [max_kslots] k-major
     double* d_panels = nullptr;
     int64_t panel_stride = 0;               // doubles per panel
     int64_t panel_kstride = 0;              // doubles per category inside a panel
@@ -92,7 +93,7 @@ struct cafe_ctx {
     std::vector<int> slot_of;               // [node*Kmax + k]
     int K_last = 0, model_last = -1;
     bool last_rejected = false, have_results = false;
-    int n_slots_last = 0;
+    int n_slots_last = 0, n_kslots_last = 0;
     int64_t last_chunk_f0 = 0, last_chunk_nf = 0;
 
     // measurement
@@ -193,7 +194,7 @@ void free_device(cafe_ctx* c) {
     if (!c->device_ready) return;            // nothing was created on a device (argument / device errors)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    hipFree(c->d_counts); hipFree(c->d_weights); hipFree(c->pool.base); hipFree(c->d_slots); hipFree(c->d_panels);
+    hipFree(c->d_counts); hipFree(c->d_weights); hipFree(c->pool.base); hipFree(c->kpool.base); hipFree(c->d_slots); hipFree(c->d_panels);
     hipFree(c->d_prior); hipFree(c->d_logprior); hipFree(c->d_catprobs); hipFree(c->d_err);
     hipFree(c->d_fam_out); hipFree(c->d_fam_lik); hipFree(c->d_cat_out); hipFree(c->d_failed);
     hipFree(c->d_scratch); hipFree(c->d_result);
@@ -311,25 +312,44 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
         HIP_TRY(c, hipMemcpy(c->d_weights, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
     }
 
-    // matrix pool: one slot per (branch, category); distinct quantized keys share a slot per call
+    // matrix pools: one slot per (branch, category); distinct quantized keys share a slot per call.
+    // Leaf branches use row-major matrices (K3 gathers a column), interior branches k-major ones (K2's A).
+    int n_leaf_branches = 0, n_inner_branches = 0;
+    for (int v = 0; v < c->n_nodes; ++v) {
+        if (v == c->root) continue;
+        (c->leaf_taxon[v] >= 0 ? n_leaf_branches : n_inner_branches) += 1;
+    }
+    c->kc = round_up(c->M + 1, kBK);
     c->pool.n = c->N;
     c->pool.ld = round_up(c->N, 16);
     c->pool.stride = (int64_t)c->N * c->pool.ld;
-    c->max_slots = (c->n_nodes - 1) * c->Kmax;
+    c->max_slots = n_leaf_branches * c->Kmax;
+    c->kpool.n = c->N;
+    c->kpool.rows = c->kc;
+    c->kpool.k_valid = c->M + 1;
+    c->kpool.kmajor = 1;
+    c->kpool.ld = round_up(c->N - 1, 16) + round_up(kMaxBM, 16) + 16;     // a row tile may start at any valid row
+    c->kpool.stride = (int64_t)c->kc * c->kpool.ld;
+    c->max_kslots = n_inner_branches * c->Kmax;
     const size_t pool_bytes = (size_t)c->max_slots * c->pool.stride * sizeof(double);
-    if (hipMalloc(&c->pool.base, pool_bytes) != hipSuccess) {
-        set_err(c, "cafe_create: cannot allocate %.2f GB for %d transition matrices of order %d", pool_bytes / 1e9, c->max_slots, c->N);
+    const size_t kpool_bytes = (size_t)std::max(1, c->max_kslots) * c->kpool.stride * sizeof(double);
+    if (hipMalloc(&c->pool.base, pool_bytes) != hipSuccess || hipMalloc(&c->kpool.base, kpool_bytes) != hipSuccess) {
+        set_err(c, "cafe_create: cannot allocate %.2f GB for %d transition matrices of order %d", (pool_bytes + kpool_bytes) / 1e9,
+                c->max_slots + c->max_kslots, c->N);
         return CAFE_ERR_MEMORY;
     }
-    HIP_TRY(c, hipMalloc(&c->d_slots, sizeof(SlotParam) * c->max_slots));
-    c->stats.matrix_bytes = (int64_t)pool_bytes;
+    // padding columns / rows of both layouts are never written by K1 and must read as 0
+    HIP_TRY(c, hipMemset(c->pool.base, 0, pool_bytes));
+    HIP_TRY(c, hipMemset(c->kpool.base, 0, kpool_bytes));
+    HIP_TRY(c, hipMalloc(&c->d_slots, sizeof(SlotParam) * (c->max_slots + c->max_kslots)));
+    c->stats.matrix_bytes = (int64_t)(pool_bytes + kpool_bytes);
 
     // per-call parameter block
     HIP_TRY(c, hipMalloc(&c->d_prior, sizeof(double) * c->R));
     HIP_TRY(c, hipMalloc(&c->d_logprior, sizeof(double) * c->R));
     HIP_TRY(c, hipMalloc(&c->d_catprobs, sizeof(double) * c->Kmax));
     if (c->n_dev > 0) HIP_TRY(c, hipMalloc(&c->d_err, sizeof(double) * (size_t)(c->M + 1) * c->n_dev));
-    c->stage_bytes = sizeof(SlotParam) * c->max_slots + sizeof(double) * (2 * (size_t)c->R + c->Kmax + (size_t)(c->M + 1) * std::max(1, c->n_dev)) + 64;
+    c->stage_bytes = sizeof(SlotParam) * (c->max_slots + c->max_kslots) + sizeof(double) * (2 * (size_t)c->R + c->Kmax + (size_t)(c->M + 1) * std::max(1, c->n_dev)) + 64;
     HIP_TRY(c, hipHostMalloc(&c->h_stage, c->stage_bytes, hipHostMallocDefault));
     HIP_TRY(c, hipHostMalloc(&c->h_result, 2 * sizeof(double), hipHostMallocDefault));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
@@ -345,7 +365,6 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     HIP_TRY(c, hipMalloc(&c->d_result, sizeof(double) * 2));
 
     // likelihood panels: rows padded so that every panel can be a GEMM B operand (kc rows) or the root (R rows)
-    c->kc = round_up(c->M + 1, kBK);
     c->rows_pad = std::max(c->kc, round_up(c->R, kBK));
     size_t free_b = 0, total_b = 0;
     HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
@@ -435,24 +454,26 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s) {
         return CAFE_OK;
     }
 
-    // ---- matrix keys: one slot per distinct (lambda_q, t_q); de-quantized like matrix_cache.cpp:148-149
+    // ---- matrix keys: one slot per distinct (lambda_q, t_q) and layout; de-quantized like matrix_cache.cpp:148-149
     char* st = c->h_stage;
     SlotParam* h_slots = reinterpret_cast<SlotParam*>(st);
-    std::map<std::pair<long, long>, int> key_slot;
-    int n_slots = 0;
+    SlotParam* h_kslots = h_slots + c->max_slots;
+    std::map<std::pair<long, long>, int> key_slot[2];
+    int n_slots = 0, n_kslots = 0;
     for (int v = 0; v < c->n_nodes; ++v) {
         if (v == c->root) continue;
+        const int layout = c->leaf_taxon[v] >= 0 ? 0 : 1;
         for (int k = 0; k < K; ++k) {
             const double mult = gamma ? pr->multipliers[k] : 1.0;
             const double lam = pr->lambdas[c->lam_idx[v]] * mult;               // lambda.h:39, :82-88
             long lq, tq;
             quantize(lam, c->blen[v], &lq, &tq);
             auto key = std::make_pair(tq, lq);
-            auto it = key_slot.find(key);
+            auto it = key_slot[layout].find(key);
             int slot;
-            if (it == key_slot.end()) {
-                slot = n_slots++;
-                key_slot.emplace(key, slot);
+            if (it == key_slot[layout].end()) {
+                slot = layout ? n_kslots++ : n_slots++;
+                key_slot[layout].emplace(key, slot);
                 const double lambda_q = double(lq) / 1000000000.0, t_q = double(tq) / 1000.0;
                 const double alpha = lambda_q * t_q / (1 + lambda_q * t_q);
                 const double coeff = 1 - 2 * alpha;
@@ -461,7 +482,7 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s) {
                 sp.oma2 = (1 - alpha) * (1 - alpha);
                 sp.zero = !(coeff > 0 && coeff != 1);       // saturated (coeff < 0) or degenerate: rows s>=1 are 0
                 sp.pad = 0;
-                h_slots[slot] = sp;
+                (layout ? h_kslots : h_slots)[slot] = sp;
             } else {
                 slot = it->second;
             }
@@ -469,8 +490,9 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s) {
         }
     }
     c->n_slots_last = n_slots;
-    c->stats.n_matrices = n_slots;
-    size_t off = sizeof(SlotParam) * (size_t)c->max_slots;
+    c->n_kslots_last = n_kslots;
+    c->stats.n_matrices = n_slots + n_kslots;
+    size_t off = sizeof(SlotParam) * (size_t)(c->max_slots + c->max_kslots);
     double* h_prior = reinterpret_cast<double*>(st + off); off += sizeof(double) * c->R;
     double* h_logprior = reinterpret_cast<double*>(st + off); off += sizeof(double) * c->R;
     double* h_cat = reinterpret_cast<double*>(st + off); off += sizeof(double) * c->Kmax;
@@ -481,7 +503,8 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s) {
         h_logprior[j] = std::log(eq);
     }
     for (int k = 0; k < K; ++k) h_cat[k] = gamma ? pr->cat_probs[k] : 1.0;
-    HIP_TRY(c, hipMemcpyAsync(c->d_slots, h_slots, sizeof(SlotParam) * n_slots, hipMemcpyHostToDevice, s));
+    if (n_slots) HIP_TRY(c, hipMemcpyAsync(c->d_slots, h_slots, sizeof(SlotParam) * n_slots, hipMemcpyHostToDevice, s));
+    if (n_kslots) HIP_TRY(c, hipMemcpyAsync(c->d_slots + c->max_slots, h_kslots, sizeof(SlotParam) * n_kslots, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->d_prior, h_prior, sizeof(double) * c->R, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->d_logprior, h_logprior, sizeof(double) * c->R, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->d_catprobs, h_cat, sizeof(double) * K, hipMemcpyHostToDevice, s));
@@ -496,6 +519,7 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s) {
     // ---- K1
     if (c->profile) HIP_TRY(c, hipEventRecord(c->ev[0], s));
     HIP_TRY(c, launch_bd_matrix_build(c->pool, c->d_slots, n_slots, s));
+    HIP_TRY(c, launch_bd_matrix_build(c->kpool, c->d_slots + c->max_slots, n_kslots, s));
     if (c->profile) HIP_TRY(c, hipEventRecord(c->ev[1], s));
 
     // ---- prune, chunk by chunk
@@ -521,12 +545,15 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s) {
                 HIP_TRY(c, launch_leaf_gather(g, K, s));
             } else {
                 GemmArgs g{};
-                g.pool = c->pool;
+                g.pool = c->kpool;
                 for (int k = 0; k < K; ++k) g.slot[k] = c->slot_of[(size_t)op.child * c->Kmax + k];
                 g.src = c->d_panels + (int64_t)op.src_panel * c->panel_stride;
-                g.dst = dst; g.panel_kstride = c->panel_kstride; g.ld = (int)cols; g.kc = c->kc;
-                g.row_off = op.to_root ? 1 : 0; g.rows = rows; g.rows_store = rows_store; g.mode = op.mode;
-                g.n_row_tiles = (rows_store + kBM - 1) / kBM;
+                g.dst = dst; g.panel_kstride = c->panel_kstride; g.ld = (int)cols; g.k_valid = c->M + 1;
+                g.rows = op.to_root ? c->R : c->M;           // parent sizes 1..rows
+                g.out_off = op.to_root ? 0 : 1;
+                g.mode = op.mode;
+                g.mi = prune_gemm_pick_mi(g.rows);
+                g.n_row_tiles = (g.rows + 16 * g.mi - 1) / (16 * g.mi);
                 g.n_col_tiles = (int)(cols / kBN);
                 if (c->profile && c->gemm_ev_used + 2 <= c->gemm_ev.size()) HIP_TRY(c, hipEventRecord(c->gemm_ev[c->gemm_ev_used++], s));
                 HIP_TRY(c, launch_prune_gemm(g, K, s));
@@ -608,7 +635,7 @@ int cafe_score_partial(cafe_ctx* ctx, const cafe_params* params, double* device_
     if (!ctx) return CAFE_ERR_ARGUMENT;
     if (!device_partial) { set_err(ctx, "cafe_score_partial: device_partial is NULL"); return CAFE_ERR_ARGUMENT; }
     try {
-        return enqueue(ctx, params, device_partial, hip_stream ? (hipStream_t)hip_stream : ctx->stream);
+        return enqueue(ctx, params, device_partial, (hipStream_t)hip_stream);
     } catch (const std::exception& e) {
         set_err(ctx, "cafe_score_partial: %s", e.what());
         return CAFE_ERR_MEMORY;
@@ -692,8 +719,20 @@ int cafe_get_matrix(cafe_ctx* ctx, int32_t node, int32_t category, double* out, 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
     const int slot = ctx->slot_of[(size_t)node * ctx->Kmax + category];
-    HIP_TRY(ctx, hipMemcpy2D(out, n * sizeof(double), ctx->pool.base + (int64_t)slot * ctx->pool.stride,
-                             (size_t)ctx->pool.ld * sizeof(double), n * sizeof(double), n, hipMemcpyDeviceToHost));
+    if (ctx->leaf_taxon[node] >= 0) {
+        HIP_TRY(ctx, hipMemcpy2D(out, n * sizeof(double), ctx->pool.base + (int64_t)slot * ctx->pool.stride,
+                                 (size_t)ctx->pool.ld * sizeof(double), n * sizeof(double), n, hipMemcpyDeviceToHost));
+        return CAFE_OK;
+    }
+    // interior branch: stored k-major, Pt[c][s-1] = P[s][c] for c <= M, s >= 1; row 0 of P is e_0 and the
+    // columns c > M are never materialised (the prune never reads them): reported as 0
+    const size_t ldt = (size_t)ctx->kpool.ld, rows = (size_t)ctx->kpool.rows;
+    std::vector<double> tmp(rows * ldt);
+    HIP_TRY(ctx, hipMemcpy(tmp.data(), ctx->kpool.base + (int64_t)slot * ctx->kpool.stride, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    std::fill(out, out + n * n, 0.0);
+    out[0] = 1.0;
+    for (size_t s2 = 1; s2 < n; ++s2)
+        for (size_t c2 = 0; c2 < n && c2 < rows; ++c2) out[s2 * n + c2] = tmp[c2 * ldt + (s2 - 1)];
     return CAFE_OK;
 }
 
@@ -724,13 +763,19 @@ int cafe_get_stats(const cafe_ctx* ctx, cafe_stats* stats) {
     return CAFE_OK;
 }
 
-int cafe_build_matrices(int32_t device, int32_t n, int32_t count, const double* lambdas, const double* ts, double* out) {
-    if (n < 1 || count < 1 || !lambdas || !ts || !out || n > bd_matrix_max_order()) return CAFE_ERR_ARGUMENT;
+int cafe_build_matrices(int32_t device, int32_t n, int32_t count, const double* lambdas, const double* ts, int32_t layout, double* out) {
+    if (n < 2 || count < 1 || !lambdas || !ts || !out || n > bd_matrix_max_order()) return CAFE_ERR_ARGUMENT;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return CAFE_ERR_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return CAFE_ERR_DEVICE;
-    MatrixPool pool;
-    pool.n = n; pool.ld = round_up(n, 16); pool.stride = (int64_t)n * pool.ld; pool.base = nullptr;
+    MatrixPool pool{};
+    pool.n = n;
+    if (layout == 0) {
+        pool.ld = round_up(n, 16); pool.stride = (int64_t)n * pool.ld; pool.kmajor = 0; pool.rows = n; pool.k_valid = n;
+    } else {
+        pool.rows = round_up(n, kBK); pool.k_valid = n; pool.kmajor = 1;
+        pool.ld = round_up(n - 1, 16) + 16; pool.stride = (int64_t)pool.rows * pool.ld;
+    }
     std::vector<SlotParam> sp(count);
     for (int i = 0; i < count; ++i) {
         long lq, tq;
@@ -742,17 +787,34 @@ int cafe_build_matrices(int32_t device, int32_t n, int32_t count, const double* 
     }
     SlotParam* d_sp = nullptr;
     int rc = CAFE_OK;
-    if (hipMalloc(&pool.base, sizeof(double) * pool.stride * count) != hipSuccess) return CAFE_ERR_MEMORY;
-    if (hipMalloc(&d_sp, sizeof(SlotParam) * count) != hipSuccess) { hipFree(pool.base); return CAFE_ERR_MEMORY; }
-    if (hipMemcpy(d_sp, sp.data(), sizeof(SlotParam) * count, hipMemcpyHostToDevice) != hipSuccess) rc = CAFE_ERR_DEVICE;
+    const size_t bytes = sizeof(double) * pool.stride * count;
+    if (hipMalloc(&pool.base, bytes) != hipSuccess) return CAFE_ERR_MEMORY;
+    if (hipMalloc(&d_sp, sizeof(SlotParam) * count) != hipSuccess) { (void)hipFree(pool.base); return CAFE_ERR_MEMORY; }
+    if (hipMemset(pool.base, 0, bytes) != hipSuccess) rc = CAFE_ERR_DEVICE;
+    if (rc == CAFE_OK && hipMemcpy(d_sp, sp.data(), sizeof(SlotParam) * count, hipMemcpyHostToDevice) != hipSuccess) rc = CAFE_ERR_DEVICE;
     if (rc == CAFE_OK && launch_bd_matrix_build(pool, d_sp, count, nullptr) != hipSuccess) rc = CAFE_ERR_DEVICE;
     if (rc == CAFE_OK && hipDeviceSynchronize() != hipSuccess) rc = CAFE_ERR_DEVICE;
-    for (int i = 0; i < count && rc == CAFE_OK; ++i)
-        if (hipMemcpy2D(out + (size_t)i * n * n, (size_t)n * sizeof(double), pool.base + (int64_t)i * pool.stride,
-                        (size_t)pool.ld * sizeof(double), (size_t)n * sizeof(double), n, hipMemcpyDeviceToHost) != hipSuccess)
-            rc = CAFE_ERR_DEVICE;
-    hipFree(pool.base);
-    hipFree(d_sp);
+    std::vector<double> tmp;
+    for (int i = 0; i < count && rc == CAFE_OK; ++i) {
+        double* o = out + (size_t)i * n * n;
+        if (layout == 0) {
+            if (hipMemcpy2D(o, (size_t)n * sizeof(double), pool.base + (int64_t)i * pool.stride, (size_t)pool.ld * sizeof(double),
+                            (size_t)n * sizeof(double), n, hipMemcpyDeviceToHost) != hipSuccess)
+                rc = CAFE_ERR_DEVICE;
+        } else {
+            tmp.resize((size_t)pool.stride);
+            if (hipMemcpy(tmp.data(), pool.base + (int64_t)i * pool.stride, tmp.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+                rc = CAFE_ERR_DEVICE;
+                break;
+            }
+            std::fill(o, o + (size_t)n * n, 0.0);
+            o[0] = 1.0;                                    // P's row 0 = e_0 is implicit in the k-major layout
+            for (int s2 = 1; s2 < n; ++s2)
+                for (int c2 = 0; c2 < n; ++c2) o[(size_t)s2 * n + c2] = tmp[(size_t)c2 * pool.ld + (s2 - 1)];
+        }
+    }
+    (void)hipFree(pool.base);
+    (void)hipFree(d_sp);
     return rc;
 }
 

@@ -15,10 +15,10 @@ namespace cafe {
 constexpr int kMaxCategories = 32;   // CAFE_MAX_CATEGORIES
 constexpr int kMaxLeafPerOp = 4;     // leaf children folded by one gather launch / one GEMM epilogue
 
-// GEMM tiling (fp64 MFMA 16x16x4, 4 waves, each a 64x64 sub-tile)
-constexpr int kBM = 128;
+// GEMM tiling (fp64 MFMA 16x16x4): block tile (16*MI) x 128, K step 16, 4 waves side by side in N
 constexpr int kBN = 128;
 constexpr int kBK = 16;
+constexpr int kMaxBM = 144;          // largest row tile (MI = 9)
 
 // Per transition matrix: a = lambda_q t_q / (1 + lambda_q t_q) of the de-quantized key
 // (matrix_cache.cpp:148-149), oma2 = (1-a)^2; zero = saturated (matrix_cache.cpp:153) or
@@ -30,29 +30,34 @@ struct SlotParam {
     int32_t pad;
 };
 
-// All matrices of a call live in one pool: slot i at base + i*stride, row-major, leading
-// dimension ld (multiple of 16, columns >= n are zero), n rows.
+// The matrices of a call live in two pools, slot i at base + i*stride (bd_matrix.hip):
+//   row-major (kmajor = 0): P[s][c], n rows, leading dimension ld (multiple of 16), columns >= n zero;
+//   k-major   (kmajor = 1): Pt[c][j] = P[j+1][c], `rows` rows (round_up(M+1, kBK); rows >= k_valid = M+1
+//                           are zero), leading dimension ld >= n-1 + one row tile, columns >= n-1 zero.
 struct MatrixPool {
     double* base;
     int64_t stride;
     int32_t ld;
-    int32_t n;
+    int32_t n;        // matrix order N = max(M,R)+1
+    int32_t rows;     // k-major: rows written
+    int32_t k_valid;  // k-major: M+1
+    int32_t kmajor;
 };
 
 // Likelihood panels: [category][row][family], family fastest, so that a node's panel is the
 // GEMM's B operand with the family axis as its N dimension.
 struct GemmArgs {
-    MatrixPool pool;
+    MatrixPool pool;                // k-major pool
     int32_t slot[kMaxCategories];   // matrix of the child's branch per category
-    const double* src;              // child panel  (chunk-relative base)
+    const double* src;              // child panel  (chunk-relative base), rows = child sizes 0..M
     double* dst;                    // parent panel (chunk-relative base)
     int64_t panel_kstride;          // doubles between categories of a panel
     int32_t ld;                     // panel leading dimension = chunk columns (multiple of kBN)
-    int32_t kc;                     // contraction extent, round_up(M+1, kBK); src rows >= M+1 are zero
-    int32_t row_off;                // 0, or 1 when the parent is the root (root index i <-> size i+1)
-    int32_t rows;                   // valid output rows: M+1, or R at the root
-    int32_t rows_store;             // rows written; rows..rows_store-1 are written as zero
+    int32_t k_valid;                // contraction extent M+1
+    int32_t rows;                   // GEMM rows = parent sizes 1..rows: M, or R when the parent is the root
+    int32_t out_off;                // panel row of parent size 1: 1 (interior parent; row 0 is copied), 0 (root)
     int32_t mode;                   // 0: dst = v, 1: dst *= v
+    int32_t mi;                     // row tile = 16*mi
     int32_t n_row_tiles;
     int32_t n_col_tiles;
 };
@@ -97,6 +102,7 @@ struct ReduceArgs {
 
 hipError_t launch_bd_matrix_build(const MatrixPool& pool, const SlotParam* d_slots, int n_slots, hipStream_t stream);
 hipError_t launch_prune_gemm(const GemmArgs& a, int n_categories, hipStream_t stream);
+int prune_gemm_pick_mi(int rows);     // row-tile height (in 16-row blocks) with the least padding
 hipError_t launch_leaf_gather(const GatherArgs& a, int n_categories, hipStream_t stream);
 hipError_t launch_root_reduce(const ReduceArgs& a, hipStream_t stream);
 // sum_f w_f * fam_out[f] and the number of failed families -> out[0], out[1]

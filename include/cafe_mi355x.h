@@ -131,9 +131,9 @@ int cafe_score(cafe_ctx* ctx, const cafe_params* params, double* neg_lnl, const 
 /* The same work for a family shard, without the final host read-back: device_partial must point
  * to 2 doubles of DEVICE memory and receives {sum_f lnL_f, number of rejected/invalid families}
  * (+inf rejection that the host can decide alone is encoded as partial[1] = 1).  The kernels are
- * enqueued on `hip_stream` (a hipStream_t, NULL = the context's own stream) and the call returns
- * without synchronising, so that the caller can all-reduce the pair across ranks (RCCL) on the
- * same stream: SURVEY.md 8e. */
+ * enqueued on `hip_stream` (a hipStream_t used as given: NULL is HIP's null stream, which is what
+ * torch.cuda.current_stream() is by default) and the call returns without synchronising, so that
+ * the caller can all-reduce the pair across ranks (RCCL) on the same stream: SURVEY.md 8e. */
 int cafe_score_partial(cafe_ctx* ctx, const cafe_params* params, double* device_partial, void* hip_stream);
 /* Turns the all-reduced pair into the scorer value: +inf if partial[1] > 0 else -partial[0]. */
 double cafe_finish_partial(const double host_partial[2]);
@@ -142,7 +142,8 @@ double cafe_finish_partial(const double host_partial[2]);
 int cafe_family_results(cafe_ctx* ctx, const cafe_family_out* out);
 
 /* Introspection for parity tests: the transition matrix the last call built for the branch above
- * `node` in category k (N x N row-major, N = max(M,R)+1: matrix_cache::get_matrix), and the root
+ * `node` in category k (N x N row-major, N = max(M,R)+1: matrix_cache::get_matrix; for an interior
+ * branch the columns c > M, which the prune never reads, are not materialised and come back 0), and the root
  * likelihood vector (R values: inference_prune's return) of family f in category k. */
 int cafe_get_matrix(cafe_ctx* ctx, int32_t node, int32_t category, double* out, size_t out_len);
 int cafe_get_root_likelihoods(cafe_ctx* ctx, int64_t family, int32_t category, double* out, size_t out_len);
@@ -152,9 +153,11 @@ int cafe_matrix_size(const cafe_ctx* ctx);
 int cafe_set_profiling(cafe_ctx* ctx, int on);
 
 /* Stand-alone kernels exposed for unit parity tests and the roofline probe. */
-/* builds `count` matrices of order n (row-major, out[count][n][n]) for (lambda[i], t[i]) pairs
- * with matrix_cache_key quantization applied (matrix_cache.h:42-61). */
-int cafe_build_matrices(int32_t device, int32_t n, int32_t count, const double* lambdas, const double* ts, double* out);
+/* builds `count` matrices of order n for (lambda[i], t[i]) pairs with matrix_cache_key quantization
+ * applied (matrix_cache.h:42-61); out[count][n][n] is always P[s][c] row-major.  layout 0: the row-major
+ * device layout leaf branches use; layout 1: the k-major layout of interior branches (built through the
+ * reversibility relation, see bd_matrix.hip), converted back on the host. */
+int cafe_build_matrices(int32_t device, int32_t n, int32_t count, const double* lambdas, const double* ts, int32_t layout, double* out);
 /* back-to-back v_mfma_f64_16x16x4_f64 issue-rate probe: returns achieved TFLOP/s on `device`. */
 int cafe_probe_fp64_mfma(int32_t device, double* tflops);
 

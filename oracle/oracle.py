@@ -83,6 +83,7 @@ def lib():
         L.orc_time_matrices.argtypes = [C.c_int, C.c_double, _f64p, C.c_int, C.c_int]
         L.orc_num_threads.restype = C.c_int
         L.orc_last_timings.argtypes = [_f64p, _f64p]
+        L.orc_set_threads.argtypes = [C.c_int]
         _lib = L
     return _lib
 
@@ -221,6 +222,22 @@ def last_timings():
     a, b = C.c_double(), C.c_double()
     lib().orc_last_timings(C.byref(a), C.byref(b))
     return a.value, b.value
+
+
+def host_cpu_share() -> int:
+    """CPUs this process may actually use: the cgroup quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def set_threads(n: int) -> None:
+    lib().orc_set_threads(int(n))
 
 
 def num_threads() -> int:
