@@ -44,13 +44,13 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
     const int wave = tid >> 6;
     const int cat = blockIdx.z;
 
-    // XCD-aware tile order: blocks b and b+8 share an XCD, so give each XCD a contiguous run of
-    // tiles; inside a run the row tiles of one column tile are adjacent and share the B panel in L2.
-    const int nblk = a.n_row_tiles * a.n_col_tiles;
-    int bid = blockIdx.x;
-    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
-    const int row_tile = bid % a.n_row_tiles;
-    const int col_tile = bid / a.n_row_tiles;
+    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch, a speed-only
+    // assumption), so XCD x takes the column tiles x, x+8, ... and runs their row tiles back to back:
+    // the row tiles of one column tile then share the child panel (B) in that XCD's L2.
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int row_tile = idx % a.n_row_tiles;
+    const int col_tile = xcd + 8 * (idx / a.n_row_tiles);
+    if (col_tile >= a.n_col_tiles) return;
     const int row0 = row_tile * BM;                        // parent size row0 + 1 is the tile's first row
     const int col0 = col_tile * kBN;
 
@@ -150,7 +150,7 @@ int prune_gemm_pick_mi(int rows) {
 }
 
 hipError_t launch_prune_gemm(const GemmArgs& a, int n_categories, hipStream_t stream) {
-    dim3 grid(a.n_row_tiles * a.n_col_tiles, 1, n_categories), block(256);
+    dim3 grid(8 * ((a.n_col_tiles + 7) / 8) * a.n_row_tiles, 1, n_categories), block(256);
     (void)hipGetLastError();
     switch (a.mi) {
         case 4: hipLaunchKernelGGL(prune_gemm_kernel<4>, grid, block, 0, stream, a); break;

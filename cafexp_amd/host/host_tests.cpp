@@ -1,0 +1,181 @@
+// CPU-only unit tests of the host adapter (no GPU, no HIP library linked): the reference's own
+// test cases for the pieces that stay on the host (test.cpp line cited per test), with mock models
+// standing in for the GPU path exactly as test.cpp:37-86 mocks `model`.
+#include <cmath>
+#include <cstdio>
+#include <iostream>
+#include <limits>
+#include <sstream>
+
+#include "cafe_host.h"
+
+using namespace cafe;
+
+static int failures = 0, checks = 0;
+#define CHECK(cond) do { ++checks; if (!(cond)) { ++failures; std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond); } } while (0)
+#define CLOSE(a, b, tol) CHECK(std::fabs((a) - (b)) <= (tol))
+
+struct mock_model : public model {                       // test.cpp:37-86
+    double value;
+    int calls = 0;
+    explicit mock_model(double v) : model(nullptr, nullptr, nullptr, 0, 0, nullptr), value(v) {}
+    double infer_family_likelihoods(root_equilibrium_distribution*, const std::map<int, int>&, const lambda*) override { ++calls; return value; }
+    std::string name() const override { return "mock"; }
+    void write_family_likelihoods(std::ostream&) override {}
+    inference_optimizer_scorer* get_lambda_optimizer(user_data&) override { return nullptr; }
+};
+
+struct quadratic_scorer : public optimizer_scorer {      // stands in for test.cpp:2289 mock_scorer
+    int calls = 0;
+    std::vector<double> initial_guesses() override { return {0.3, -0.2}; }
+    double calculate_score(const double* v) override { ++calls; return 5 + (v[0] - 1.25) * (v[0] - 1.25) + 3 * (v[1] + 0.5) * (v[1] + 0.5); }
+};
+struct inf_scorer : public optimizer_scorer {
+    std::vector<double> initial_guesses() override { return {0.1}; }
+    double calculate_score(const double*) override { return std::numeric_limits<double>::infinity(); }
+};
+
+static void test_newick() {
+    std::unique_ptr<clade> t(parse_newick("(A:1,B:3):7"));                       // test.cpp:1642
+    CHECK(t->descendants().size() == 2 && t->get_taxon_name() == "AB" && t->get_branch_length() == 7);
+    auto bl = t->get_branch_lengths();
+    CHECK(bl.size() == 3 && bl.count(7.0) == 1);
+    std::unique_ptr<clade> u(parse_newick("((E:0.36,D:0.30)abc:1.00,(C:0.85,(A:0.59,B:0.35):0.42):0.39);"));
+    CHECK(u->leaves().size() == 5 && u->find_descendant("AB") != nullptr && u->get_taxon_name() == "ABCDE");
+    std::vector<std::string> order;                                               // children before parents
+    u->apply_reverse_level_order([&](const clade* c) { order.push_back(c->get_taxon_name()); });
+    CHECK(order.back() == "ABCDE" && order.size() == 9);
+    bool threw = false;
+    try { std::unique_ptr<clade> bad(parse_newick("(A:1,B:0);")); } catch (std::runtime_error&) { threw = true; }
+    CHECK(threw);
+    std::unique_ptr<clade> l(parse_newick("((A:1,B:1):2,C:1);", true));          // lambda tree: index map is index-1
+    auto m = l->get_lambda_index_map();
+    CHECK(m["A"] == 0 && m["AB"] == 1 && m["ABC"] == 0 && l->get_lambda_index() == 1);
+    threw = false;
+    try { l->get_branch_length(); } catch (std::runtime_error&) { threw = true; }
+    CHECK(threw);
+}
+
+static void test_families_and_sizes() {
+    std::istringstream in("Desc\tFamily ID\tA\tB\n\t (null)1\t5\t10\n\t (null)2\t5\t7\n\t (null)3\t5\t10\n\t (null)4\t5\t7\n");   // test.cpp:1626
+    std::vector<gene_family> fams;
+    read_gene_families(in, nullptr, fams);
+    CHECK(fams.size() == 4 && fams[0].get_species_size("a") == 5 && fams[0].get_species_size("B") == 10);
+    CHECK(fams[0].species_size_match(fams[2]) && !fams[0].species_size_match(fams[1]));
+    int M = -1, R = -1;
+    compute_max_sizes(fams, M, R);
+    CHECK(M == 60 && R == 30);
+    gene_family big;
+    big.set_species_size("x", 90);
+    std::vector<gene_family> one{big};
+    M = R = -1;
+    compute_max_sizes(one, M, R);
+    CHECK(M == 140 && R == 112);
+    std::unique_ptr<clade> t(parse_newick("((A:1,B:1):1,(C:1,D:1):1);"));
+    gene_family f;
+    f.set_species_size("A", 1); f.set_species_size("B", 0); f.set_species_size("C", 0); f.set_species_size("D", 0);
+    CHECK(!f.exists_at_root(t.get()));
+    f.set_species_size("D", 2);
+    CHECK(f.exists_at_root(t.get()));
+}
+
+static void test_error_model() {
+    std::istringstream in("maxcnt: 20\ncntdiff: -1 0 1\n0 0.0 0.8 0.2\n1 0.2 0.6 0.2\n20 0.2 0.6 0.2\n");               // test.cpp:1745
+    error_model em;
+    read_error_model_file(in, &em);
+    CHECK(em.n_deviations() == 3 && em.get_max_family_size() == 21);
+    CHECK(em.get_probs(3) == std::vector<double>({0.2, 0.6, 0.2}) && em.get_probs(0) == std::vector<double>({0.0, 0.8, 0.2}));
+    // lambda_epsilon_optimizer (test.cpp:2178): rows {0,.94,.06} / {.06,.88,.06} style replacement by value
+    error_model e2;
+    e2.set_probabilities(0, {.0, .7, .3});
+    e2.set_probabilities(1, {.4, .2, .4});
+    mock_model m(0.0);
+    single_lambda lam(0.05);
+    uniform_distribution prior;
+    std::map<int, int> rd;
+    lambda_epsilon_optimizer opt(&m, &e2, &prior, rd, &lam, 10);
+    opt.initial_guesses();
+    std::vector<double> values = {0.05, 0.06, 0.04};                     // lambda, then epsilons in sorted order (.3 -> .06, .4 -> .04)
+    opt.calculate_score(values.data());
+    CHECK(e2.get_probs(0) == std::vector<double>({0, .94, .06}));
+    CHECK(e2.get_probs(1) == std::vector<double>({.04, .92, .04}));
+    bool threw = false;
+    try { error_model bad; bad.set_probabilities(0, {0.1, 0.8, 0.1}); } catch (std::runtime_error&) { threw = true; }
+    CHECK(threw);
+}
+
+static void test_priors_and_gamma() {
+    root_distribution rd;
+    rd.vectorize_uniform(10);
+    uniform_distribution u;
+    u.initialize(&rd);
+    CLOSE(u.compute(5), 0.1, 1e-4);                                      // test.cpp:549
+    CHECK(u.compute(10) == 0);
+    root_distribution r112;
+    r112.vectorize_uniform(112);
+    u.initialize(&r112);
+    CHECK((double)u.compute(0) == 0.0089285718277096748);                // float(1)/float(112)
+    std::vector<double> probs(4), mult(4);
+    get_gamma(probs, mult, 0.25);                                        // SURVEY 8c oracle values (compiled reference)
+    CLOSE(mult[0], 0.0021117569167044, 1e-15);
+    CLOSE(mult[1], 0.06668995694102, 1e-14);
+    CLOSE(mult[2], 0.50148567146622, 1e-13);
+    CLOSE(mult[3], 3.4297126146761, 1e-12);
+    CHECK(probs[0] == 0.25 && probs[3] == 0.25);
+}
+
+static void test_scorers() {
+    // NaN from the model becomes +inf (test.cpp:2250)
+    mock_model nan_model(std::nan(""));
+    single_lambda lam(0.05);
+    uniform_distribution prior;
+    std::map<int, int> rd;
+    lambda_optimizer opt(&lam, &nan_model, &prior, 7, rd);
+    double v = 0.05;
+    CHECK(std::isinf(opt.calculate_score(&v)));
+    // lambda_optimizer plumbs the value into the lambda object; initial guess is positive
+    mock_model ok(1000.0);
+    lambda_optimizer o2(&lam, &ok, &prior, 10, rd);
+    double v2 = 0.0123;
+    CHECK(o2.calculate_score(&v2) == 1000.0 && lam.get_single_lambda() == 0.0123);
+    randomizer_engine.seed(10);
+    auto g = o2.initial_guesses();
+    CHECK(g.size() == 1 && g[0] > 0);
+    // multiple lambda validity (test.cpp:1915) and lookup by node name
+    std::map<std::string, int> idx{{"A", 0}, {"B", 1}, {"AB", 0}};
+    multiple_lambda ml(idx, {0.03, 0.05});
+    std::unique_ptr<clade> t(parse_newick("(A:1,B:2);"));
+    CHECK(ml.get_value_for_clade(t->find_descendant("B")) == 0.05 && ml.is_valid());
+    double neg[2] = {0.01, -0.01};
+    ml.update(neg);
+    CHECK(!ml.is_valid());
+    single_lambda zero(0.0);
+    CHECK(!zero.is_valid());
+}
+
+static void test_optimizer() {
+    quadratic_scorer q;
+    optimizer o(&q);
+    o.similarity_window = 0;
+    auto r = o.optimize();
+    CLOSE(r.values[0], 1.25, 1e-4);
+    CLOSE(r.values[1], -0.5, 1e-4);
+    CLOSE(r.score, 5.0, 1e-8);
+    CHECK(r.num_scorer_calls == q.calls && r.num_iterations > 10);
+    inf_scorer bad;
+    optimizer ob(&bad);
+    bool threw = false;
+    try { ob.optimize(); } catch (std::runtime_error&) { threw = true; }   // OptimizerInitializationFailure after 100 retries
+    CHECK(threw);
+}
+
+int main() {
+    test_newick();
+    test_families_and_sizes();
+    test_error_model();
+    test_priors_and_gamma();
+    test_scorers();
+    test_optimizer();
+    std::printf("%d checks, %d failures\n", checks, failures);
+    return failures ? 1 : 0;
+}
