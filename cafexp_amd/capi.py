@@ -62,7 +62,7 @@ class CafeStats(C.Structure):
 EXPORTS = [
     "cafe_abi_version", "cafe_create", "cafe_destroy", "cafe_last_error", "cafe_score", "cafe_score_partial",
     "cafe_finish_partial", "cafe_family_results", "cafe_get_matrix", "cafe_get_root_likelihoods", "cafe_get_stats",
-    "cafe_matrix_size", "cafe_build_matrices", "cafe_probe_fp64_mfma", "cafe_set_profiling",
+    "cafe_matrix_size", "cafe_build_matrices", "cafe_probe_fp64_mfma", "cafe_set_profiling", "cafe_debug_stamps",
 ]
 
 _lib = None
@@ -115,6 +115,8 @@ def load():
     L.cafe_build_matrices.argtypes = [C.c_int32, C.c_int32, C.c_int32, _f64p, _f64p, C.c_int32, _f64p]
     L.cafe_probe_fp64_mfma.restype = C.c_int
     L.cafe_probe_fp64_mfma.argtypes = [C.c_int32, _f64p]
+    L.cafe_debug_stamps.restype = C.c_int
+    L.cafe_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t]
     L.cafe_set_profiling.restype = C.c_int
     L.cafe_set_profiling.argtypes = [C.c_void_p, C.c_int]
     _lib = L
@@ -248,6 +250,11 @@ class Context:
         st = CafeStats()
         self._check(self._lib.cafe_get_stats(self._h, C.byref(st)))
         return st.as_dict()
+
+    def debug_stamps(self, words: int) -> np.ndarray:
+        out = np.zeros(words, dtype=np.uint64)
+        self._check(self._lib.cafe_debug_stamps(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), words))
+        return out
 
     def set_profiling(self, on: bool):
         self._check(self._lib.cafe_set_profiling(self._h, 1 if on else 0))

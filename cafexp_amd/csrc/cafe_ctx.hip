@@ -17,6 +17,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <limits>
 #include <map>
 #include <string>
@@ -82,6 +83,8 @@ struct cafe_ctx {
     double* d_scratch = nullptr;
     int n_scratch = 1024;
     double* d_result = nullptr;
+    unsigned long long* d_stamps = nullptr;     // diagnostic block timeline of the LAST K2 launch (CAFE_GEMM_STAMPS=1)
+    size_t stamps_words = 0;
     // pinned staging
     char* h_stage = nullptr;
     size_t stage_bytes = 0;
@@ -158,23 +161,32 @@ int emit_node(cafe_ctx* c, int v, const std::vector<int>& need, PanelAlloc& pa) 
     for (int u : order) panel_of[u] = emit_node(c, u, need, pa);
     const int dst = pa.get();
     bool init = false;
-    for (size_t i = 0; i < leaves.size(); i += kMaxLeafPerOp) {
-        Op op{};
-        op.type = 0;
-        op.dst_panel = dst;
-        op.n_leaf = (int)std::min<size_t>(kMaxLeafPerOp, leaves.size() - i);
-        for (int l = 0; l < op.n_leaf; ++l) op.leaf_node[l] = leaves[i + l];
-        op.mode = init ? 1 : 0;
-        op.to_root = (v == c->root);
-        c->ops.push_back(op);
-        init = true;
-    }
-    for (int u : inner) {      // child order of the reference (probability.cpp:205 walks _descendants in order)
+    // A parent with interior children folds (up to kMaxLeafPerOp of) its leaf children into the epilogue of
+    // the first GEMM; a parent with leaf children only (a cherry) is a pure gather.  Extra leaves gather-multiply.
+    // (one leaf, and only without an error model: the specialised epilogue of prune_gemm.hip)
+    size_t fused = (inner.empty() || leaves.empty() || c->n_dev > 0) ? 0 : 1;
+    for (size_t gi = 0; gi < inner.size(); ++gi) {   // child order of the reference (probability.cpp:205 walks _descendants in order)
+        const int u = inner[gi];
         Op op{};
         op.type = 1;
         op.dst_panel = dst;
         op.src_panel = panel_of[u];
         op.child = u;
+        op.mode = init ? 1 : 0;
+        op.to_root = (v == c->root);
+        if (gi == 0) {
+            op.n_leaf = (int)fused;
+            for (size_t l = 0; l < fused; ++l) op.leaf_node[l] = leaves[l];
+        }
+        c->ops.push_back(op);
+        init = true;
+    }
+    for (size_t i = fused; i < leaves.size(); i += kMaxLeafPerOp) {
+        Op op{};
+        op.type = 0;
+        op.dst_panel = dst;
+        op.n_leaf = (int)std::min<size_t>(kMaxLeafPerOp, leaves.size() - i);
+        for (int l = 0; l < op.n_leaf; ++l) op.leaf_node[l] = leaves[i + l];
         op.mode = init ? 1 : 0;
         op.to_root = (v == c->root);
         c->ops.push_back(op);
@@ -363,6 +375,11 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     HIP_TRY(c, hipMemset(c->d_failed, 0, sizeof(int32_t) * c->Fp));
     HIP_TRY(c, hipMalloc(&c->d_scratch, sizeof(double) * 2 * c->n_scratch));
     HIP_TRY(c, hipMalloc(&c->d_result, sizeof(double) * 2));
+    if (std::getenv("CAFE_GEMM_STAMPS")) {
+        c->stamps_words = (size_t)6 * 8 * ((c->Fp / kBN + 8) * 16) * c->Kmax;
+        HIP_TRY(c, hipMalloc(&c->d_stamps, c->stamps_words * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMemset(c->d_stamps, 0, c->stamps_words * sizeof(unsigned long long)));
+    }
 
     // likelihood panels: rows padded so that every panel can be a GEMM B operand (kc rows) or the root (R rows)
     c->rows_pad = std::max(c->kc, round_up(c->R, kBK));
@@ -555,6 +572,16 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s) {
                 g.mi = prune_gemm_pick_mi(g.rows);
                 g.n_row_tiles = (g.rows + 16 * g.mi - 1) / (16 * g.mi);
                 g.n_col_tiles = (int)(cols / kBN);
+                { const char* sl = std::getenv("CAFE_GEMM_STAMPS_LAUNCH"); const long want = sl ? std::atol(sl) : -1;
+                  g.stamps = (want < 0 || want == (long)c->stats.gemm_launches) ? c->d_stamps : nullptr; }
+                g.lpool = c->pool;
+                g.n_leaf = op.n_leaf;
+                for (int l = 0; l < op.n_leaf; ++l) {
+                    g.taxon[l] = c->leaf_taxon[op.leaf_node[l]];
+                    for (int k = 0; k < K; ++k) g.leaf_slot[l][k] = c->slot_of[(size_t)op.leaf_node[l] * c->Kmax + k];
+                }
+                g.counts = c->d_counts; g.counts_ld = c->Fp; g.f0 = f0;
+                g.err = c->n_dev > 0 ? c->d_err : nullptr; g.n_dev = c->n_dev; g.max_family_size = c->M;
                 if (c->profile && c->gemm_ev_used + 2 <= c->gemm_ev.size()) HIP_TRY(c, hipEventRecord(c->gemm_ev[c->gemm_ev_used++], s));
                 HIP_TRY(c, launch_prune_gemm(g, K, s));
                 if (c->profile && c->gemm_ev_used + 1 <= c->gemm_ev.size()) HIP_TRY(c, hipEventRecord(c->gemm_ev[c->gemm_ev_used++], s));
@@ -700,6 +727,12 @@ int cafe_family_results(cafe_ctx* ctx, const cafe_family_out* out) {
 }
 
 int cafe_matrix_size(const cafe_ctx* ctx) { return ctx ? ctx->N : 0; }
+
+int cafe_debug_stamps(cafe_ctx* ctx, unsigned long long* out, size_t words) {
+    if (!ctx || !ctx->d_stamps || !out) return CAFE_ERR_STATE;
+    if (words > ctx->stamps_words) words = ctx->stamps_words;
+    return hipMemcpy(out, ctx->d_stamps, words * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? CAFE_OK : CAFE_ERR_DEVICE;
+}
 
 int cafe_set_profiling(cafe_ctx* ctx, int on) {
     if (!ctx) return CAFE_ERR_ARGUMENT;

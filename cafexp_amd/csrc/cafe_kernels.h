@@ -60,6 +60,18 @@ struct GemmArgs {
     int32_t mi;                     // row tile = 16*mi
     int32_t n_row_tiles;
     int32_t n_col_tiles;
+    unsigned long long* stamps;     // diagnostic: 6 words per block (placement + timeline), nullptr in production
+    // leaf siblings folded into the epilogue (K3's work for a parent with leaf and interior children)
+    MatrixPool lpool;               // row-major pool
+    int32_t n_leaf;
+    int32_t taxon[kMaxLeafPerOp];
+    int32_t leaf_slot[kMaxLeafPerOp][kMaxCategories];
+    const int32_t* counts;          // [taxon][family] for the whole shard
+    int64_t counts_ld;
+    int64_t f0;                     // first family of the chunk
+    const double* err;              // [(M+1)][n_dev] or nullptr
+    int32_t n_dev;
+    int32_t max_family_size;
 };
 
 struct GatherArgs {

@@ -8,9 +8,10 @@
 // child's likelihood panel, so the branch is ONE dense fp64 GEMM per category
 //     C[s, f] = sum_{c=0..M} P_child[s][c] * L_child[c, f],     s = 1..M  (1..R under the root)
 // and the child product (probability.cpp:211-218, 233-240) is the epilogue: the first child of a
-// parent stores C, later children multiply into the parent panel.  Parent size 0 is not part of
-// the GEMM: P[0][c] = delta(c,0) (matrix_cache.cpp:70-77), so that row is a copy of the child's
-// row 0, done by the blocks of the first row tile.
+// parent stores C, later children multiply into the parent panel, and ONE leaf sibling can be
+// folded in as well (its factor is a gathered column of its matrix, K3's job otherwise).
+// Parent size 0 is not part of the GEMM: P[0][c] = delta(c,0) (matrix_cache.cpp:70-77), so that
+// row is a copy of the child's row 0, done by the blocks of the first row tile.
 //
 // Operands: A = the branch's k-major matrix Pt[c][s-1] (bd_matrix.hip), B = the child panel
 // [c][family]; both tiles are [16 k][row/col] images filled by LDS-DMA (global_load_lds_dwordx4,
@@ -21,6 +22,16 @@
 // accumulator tiles of v_mfma_f64_16x16x4_f64 in VGPRs (AGPR accumulators halve the issue rate of
 // the f64 MFMA on gfx950).  MI is chosen per launch to minimise row padding
 // (M = 720 -> MI = 9: 5 tiles of 144 rows, no padding).  Bound: fp64 MFMA.
+//
+// Two measured facts shape the code (tools/gemm_timeline.py, tools/fp64_probe2.hip):
+//  * a wave whose next MFMA is waiting for the matrix pipe holds the SIMD's vector issue port: the
+//    co-resident workgroup's VALU instructions crawl (one per ~16 MFMAs).  Everything outside the
+//    MFMA stream is therefore written to need almost no VALU: uniform bases in SGPRs + one 32-bit
+//    per-lane offset, compile-time specialised epilogues, no per-element branches;
+//  * the accumulator array must only be indexed by compile-time constants, or it is demoted to
+//    scratch memory (5x slower).  `make check` fails the build if a K2 instantiation uses scratch.
+#include <type_traits>
+
 #include "cafe_kernels.h"
 
 namespace cafe {
@@ -32,7 +43,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr int kBStride = kBN + 16;                        // 144 doubles
 constexpr int a_stride(int bm) { return (bm % 32 == 16) ? bm : bm + 16; }
 
-template <int MI>
+// MI: row tile = 16*MI.  MUL: multiply into the parent panel instead of storing.  LEAF: one leaf
+// sibling (no error model) is folded into the epilogue.
+template <int MI, bool MUL, bool LEAF>
 __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
     constexpr int BM = 16 * MI;
     constexpr int SA = a_stride(BM);
@@ -41,8 +54,10 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: LDS-DMA bases (M0) need no VALU
     const int cat = blockIdx.z;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if (a.stamps) st0 = __builtin_amdgcn_s_memrealtime();
 
     // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch, a speed-only
     // assumption), so XCD x takes the column tiles x, x+8, ... and runs their row tiles back to back:
@@ -60,23 +75,47 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
     const int lda = a.pool.ld;
     const int ldb = a.ld;
 
-    // LDS-DMA: wave w fills k-rows w, w+4, w+8, w+12 of both tiles; a row is 1 KB pieces of 64 x 16 B
-    auto stage = [&](int k0, int buf) {
+    // LDS-DMA fill of one tile pair, issued in four quarters (one per k-step) so that the issue slots
+    // fall in the shadow of the MFMAs.  16 slots = 4 quarters x 4 waves.  B: k-row `slot` is one 1 KB piece.
+    // A: with SA == BM the [16][BM] image is contiguous, 2*MI pieces of 1 KB laid end to end (a piece may
+    // span two k-rows; the per-lane source address makes that free); slot s moves pieces s, s+16, ...
+    // and wraps, re-writing an identical piece rather than branching.  With a padded row (even MI) each
+    // k-row is moved on its own with the tail lanes masked off.  Source addresses are a uniform row
+    // base plus a per-lane 32-bit offset that is computed once.
+    constexpr bool A_CONTIG = (SA == BM);
+    constexpr int NP = 2 * MI, PER = (NP + 15) / 16;
+    unsigned a_src[4][PER > 0 ? PER : 1];
+    int a_dst[4][PER > 0 ? PER : 1];
+    if (A_CONTIG) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                int piece = q * 4 + wave + 16 * j;
+                if (piece >= NP) piece -= NP;
+                const int e = piece * 128 + lane * 2;          // element of the tile image this lane moves
+                a_src[q][j] = (unsigned)((e / BM) * lda + (e % BM));
+                a_dst[q][j] = piece * 128;
+            }
+    }
+    const unsigned lane2 = (unsigned)lane * 2;
+    auto stage_quarter = [&](int k0, int buf, int q) {
         double* As = lds + buf * (A_TILE + B_TILE);
         double* Bs = As + A_TILE;
+        const int krow = q * 4 + wave;
+        if (A_CONTIG) {
+            const double* ga = A + (int64_t)k0 * lda;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int krow = wave + 4 * r;
+            for (int j = 0; j < PER; ++j)
+                __builtin_amdgcn_global_load_lds((gptr_t)(ga + a_src[q][j]), (lptr_t)(As + a_dst[q][j]), 16, 0, 0);
+        } else {
             const double* ga = A + (int64_t)(k0 + krow) * lda;
-#pragma unroll
-            for (int off = 0; off < BM; off += 128) {
-                const int nl = (BM - off) >= 128 ? 64 : (BM - off) / 2;
-                if (lane < nl)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(ga + off + lane * 2), (lptr_t)(As + krow * SA + off), 16, 0, 0);
-            }
-            const double* gb = B + (int64_t)(k0 + krow) * ldb;
-            __builtin_amdgcn_global_load_lds((gptr_t)(gb + lane * 2), (lptr_t)(Bs + krow * kBStride), 16, 0, 0);
+            constexpr int nl = BM >= 128 ? 64 : BM / 2;
+            if (nl == 64 || lane < nl)
+                __builtin_amdgcn_global_load_lds((gptr_t)(ga + lane2), (lptr_t)(As + krow * SA), 16, 0, 0);
         }
+        const double* gb = B + (int64_t)(k0 + krow) * ldb;
+        __builtin_amdgcn_global_load_lds((gptr_t)(gb + lane2), (lptr_t)(Bs + krow * kBStride), 16, 0, 0);
     };
 
     double4_t acc[MI][2];
@@ -88,54 +127,148 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
 
     const int l15 = lane & 15, l4 = lane >> 4;
     const int n_k = (a.k_valid + kBK - 1) / kBK;
+    const int a_off = l4 * SA + l15;
+    const int b_off = A_TILE + l4 * kBStride + wave * 32 + l15;
 
-    stage(0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) stage_quarter(0, 0, q);
     __syncthreads();                                       // vmcnt(0) + barrier: tile 0 has landed
-    for (int kt = 0; kt < n_k; ++kt) {
+    if (a.stamps) st1 = __builtin_amdgcn_s_memrealtime();
+
+    // One K tile (rows c > M of the k-major matrix are zero, so padded k inside a step adds exact zeros;
+    // whole padded k-steps of the last tile are skipped).  Before the MFMAs of step s are issued, the DMA quarter of
+    // the next tile and the fragment reads of step s+1 (second register set) are already in flight, so a
+    // workgroup that has the SIMD to itself (its partner in prologue/epilogue) does not expose the LDS
+    // latency four times per tile.
+    double af[2][MI], bf[2][2];
+    auto load_frags = [&](const double* base, int s4, int set) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[set][i] = base[a_off + s4 * 4 * SA + i * 16];
+        bf[set][0] = base[b_off + s4 * 4 * kBStride];
+        bf[set][1] = base[b_off + s4 * 4 * kBStride + 16];
+    };
+    auto tile = [&](int kt, auto stage_next, int n_steps) {
         const int buf = kt & 1;
-        if (kt + 1 < n_k) stage((kt + 1) * kBK, buf ^ 1);
-        const double* As = lds + buf * (A_TILE + B_TILE) + l4 * SA + l15;
-        const double* Bs = lds + buf * (A_TILE + B_TILE) + A_TILE + l4 * kBStride + wave * 32 + l15;
-        // every k-step of a tile is executed: rows c > M of the k-major matrix are zero, so the
-        // padded steps of the last tile add exact zeros (and keep the loop free of branches)
+        const double* cur = lds + buf * (A_TILE + B_TILE);
+        load_frags(cur, 0, 0);
 #pragma unroll
-        for (int kk = 0; kk < kBK; kk += 4) {
-            double af[MI], bf[2];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = As[kk * SA + i * 16];
-            bf[0] = Bs[kk * kBStride];
-            bf[1] = Bs[kk * kBStride + 16];
+        for (int s4 = 0; s4 < 4; ++s4) {
+            if (!decltype(stage_next)::value && s4 >= n_steps) break;      // last tile: skip all-padding k-steps
+            if (decltype(stage_next)::value) stage_quarter((kt + 1) * kBK, buf ^ 1, s4);
+            if (s4 < 3) load_frags(cur, s4 + 1, (s4 + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[0], acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[1], acc[i][1], 0, 0, 0);
+                acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s4 & 1][i], bf[s4 & 1][0], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s4 & 1][i], bf[s4 & 1][1], acc[i][1], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();                                   // next tile landed, this one fully read
-    }
+    };
+    for (int kt = 0; kt + 1 < n_k; ++kt) tile(kt, std::true_type{}, 4);
+    tile(n_k - 1, std::false_type{}, (a.k_valid - (n_k - 1) * kBK + 3) / 4);
+    if (a.stamps) st2 = __builtin_amdgcn_s_memrealtime();
 
-    // epilogue: C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+    // ---- epilogue.  C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg,
+    // i.e. a lane holds single columns.  Each 16-row block of the wave's 16*MI x 32 sub-tile goes through a
+    // small private LDS image so that a lane then owns two adjacent columns of one row: stores (and the
+    // loads of the multiply mode) are 16 B per lane, 256 B contiguous per row.  All addresses are
+    // `uniform base + per-lane 32-bit offset`; the old panel values (MUL) and the leaf factor (LEAF) of
+    // row block i+1 are loaded before block i is staged and stored.
+    constexpr int SS = 34;                                  // staging row stride (doubles)
+    double* stg = lds + wave * (16 * SS);
+    const int e_row = lane >> 4, e_col = (lane & 15) * 2;   // row inside a group of 4, first of two columns
+    const int gcol = wave * 32 + e_col;                     // column inside the block tile
+    double* const Ct = C + (int64_t)(row0 + a.out_off) * ldb;                 // uniform: tile's first output row
+    const unsigned c_lane = (unsigned)(e_row * ldb + gcol);                    // per-lane element offset
+    const double* Lt = nullptr;                                                // leaf matrix rows of this tile
+    unsigned l_lane0 = 0, l_lane1 = 0;
+    if (LEAF) {
+        const int32_t* cnt = a.counts + (int64_t)a.taxon[0] * a.counts_ld + a.f0 + col0 + gcol;
+        Lt = a.lpool.base + (int64_t)a.leaf_slot[0][cat] * a.lpool.stride + (int64_t)(row0 + 1) * a.lpool.ld;   // parent size row0+1
+        l_lane0 = (unsigned)(e_row * a.lpool.ld + cnt[0]);
+        l_lane1 = (unsigned)(e_row * a.lpool.ld + cnt[1]);
+    }
+    const int ldl = a.lpool.ld;
+    const int rows_here = a.rows - row0;                    // valid rows of this tile (>= BM for interior tiles)
+    struct Pre { double2 f[4]; };
+    // FULL: the tile has all BM rows (always true when 16*MI divides the row count): no per-row masks
+    auto prefetch = [&](int i, Pre& p, auto full) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = row0 + i * 16 + l4 + 4 * r;    // parent size row + 1
-            if (row < a.rows) {
-                double* crow = C + (int64_t)(row + a.out_off) * ldb + wave * 32 + l15;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    double v = acc[i][j][r];
-                    if (a.mode) v *= crow[j * 16];
-                    crow[j * 16] = v;
+        for (int q = 0; q < 4; ++q) {
+            const int step = i * 16 + q * 4;                // uniform
+            double2 f = make_double2(1.0, 1.0);
+            if (decltype(full)::value || step + e_row < rows_here) {
+                if (LEAF) {
+                    const double* lr = Lt + (int64_t)step * ldl;
+                    f.x = lr[l_lane0];
+                    f.y = lr[l_lane1];
+                }
+                if (MUL) {
+                    const double2 old = *reinterpret_cast<const double2*>(Ct + (int64_t)step * ldb + c_lane);
+                    f.x *= old.x;
+                    f.y *= old.y;
                 }
             }
+            p.f[q] = f;
         }
+    };
+    auto flush = [&](int i, const Pre& p, auto full) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stg[(l4 + 4 * r) * SS + j * 16 + l15] = acc[i][j][r];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double2 v = *reinterpret_cast<const double2*>(&stg[(q * 4 + e_row) * SS + e_col]);
+            const int step = i * 16 + q * 4;
+            if (decltype(full)::value || step + e_row < rows_here) {
+                if (MUL || LEAF) {
+                    v.x *= p.f[q].x;
+                    v.y *= p.f[q].y;
+                }
+                *reinterpret_cast<double2*>(Ct + (int64_t)step * ldb + c_lane) = v;
+            }
+        }
+    };
+    auto epilogue = [&](auto full) {
+        Pre pre[2];
+        if (MUL || LEAF) prefetch(0, pre[0], full);
+        // full unroll is mandatory: a runtime i would index the accumulator array dynamically and demote
+        // it to scratch memory
+#pragma clang loop unroll(full)
+        for (int i = 0; i < MI; ++i) {
+            if ((MUL || LEAF) && i + 1 < MI) prefetch(i + 1, pre[(i + 1) & 1], full);
+            flush(i, pre[i & 1], full);
+        }
+    };
+    if (rows_here >= BM) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
+    // parent size 0 only reaches child size 0 (P[0][c] = delta(c,0)): that panel row is the child's row 0,
+    // times the leaf sibling's P_leaf[0][x] = delta(x,0)
+    if (a.out_off == 1 && row_tile == 0 && tid < kBN / 2) {
+        const int c2 = tid * 2;
+        double2 v = *reinterpret_cast<const double2*>(B + c2);
+        if (LEAF) {
+            const int32_t* cnt = a.counts + (int64_t)a.taxon[0] * a.counts_ld + a.f0 + col0 + c2;
+            v.x = cnt[0] == 0 ? v.x : 0.0;
+            v.y = cnt[1] == 0 ? v.y : 0.0;
+        }
+        double2* dst = reinterpret_cast<double2*>(C + c2);
+        if (MUL) {
+            const double2 old = *dst;
+            v.x *= old.x;
+            v.y *= old.y;
+        }
+        *dst = v;
     }
-    // parent size 0 only reaches child size 0 with probability 1: copy the child's row 0
-    if (a.out_off == 1 && row_tile == 0 && tid < kBN) {
-        double v = B[tid];
-        if (a.mode) v *= C[tid];
-        C[tid] = v;
+    if (a.stamps && tid == 0) {             // diagnostic build only: per-block timeline (100 MHz ticks) + placement
+        const unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* o = a.stamps + 6 * ((size_t)blockIdx.z * gridDim.x + blockIdx.x);
+        o[0] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
+        o[1] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
+        o[2] = st0; o[3] = st1; o[4] = st2; o[5] = st3;
     }
 }
 
@@ -149,16 +282,29 @@ int prune_gemm_pick_mi(int rows) {
     return best;
 }
 
+template <int MI>
+static void launch_mi(const GemmArgs& a, dim3 grid, hipStream_t stream) {
+    const dim3 block(256);
+    if (a.mode) {
+        if (a.n_leaf) hipLaunchKernelGGL((prune_gemm_kernel<MI, true, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((prune_gemm_kernel<MI, true, false>), grid, block, 0, stream, a);
+    } else {
+        if (a.n_leaf) hipLaunchKernelGGL((prune_gemm_kernel<MI, false, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((prune_gemm_kernel<MI, false, false>), grid, block, 0, stream, a);
+    }
+}
+
 hipError_t launch_prune_gemm(const GemmArgs& a, int n_categories, hipStream_t stream) {
-    dim3 grid(8 * ((a.n_col_tiles + 7) / 8) * a.n_row_tiles, 1, n_categories), block(256);
+    if (a.n_leaf > 1 || (a.n_leaf == 1 && a.err != nullptr)) return hipErrorInvalidValue;   // the schedule never asks for it
+    dim3 grid(8 * ((a.n_col_tiles + 7) / 8) * a.n_row_tiles, 1, n_categories);
     (void)hipGetLastError();
     switch (a.mi) {
-        case 4: hipLaunchKernelGGL(prune_gemm_kernel<4>, grid, block, 0, stream, a); break;
-        case 5: hipLaunchKernelGGL(prune_gemm_kernel<5>, grid, block, 0, stream, a); break;
-        case 6: hipLaunchKernelGGL(prune_gemm_kernel<6>, grid, block, 0, stream, a); break;
-        case 7: hipLaunchKernelGGL(prune_gemm_kernel<7>, grid, block, 0, stream, a); break;
-        case 8: hipLaunchKernelGGL(prune_gemm_kernel<8>, grid, block, 0, stream, a); break;
-        case 9: hipLaunchKernelGGL(prune_gemm_kernel<9>, grid, block, 0, stream, a); break;
+        case 4: launch_mi<4>(a, grid, stream); break;
+        case 5: launch_mi<5>(a, grid, stream); break;
+        case 6: launch_mi<6>(a, grid, stream); break;
+        case 7: launch_mi<7>(a, grid, stream); break;
+        case 8: launch_mi<8>(a, grid, stream); break;
+        case 9: launch_mi<9>(a, grid, stream); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

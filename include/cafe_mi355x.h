@@ -151,6 +151,8 @@ int cafe_get_stats(const cafe_ctx* ctx, cafe_stats* stats);
 int cafe_matrix_size(const cafe_ctx* ctx);
 /* 1 (default): bracket every K2 launch with HIP events so that cafe_stats.ms_gemm is measured; 0: off. */
 int cafe_set_profiling(cafe_ctx* ctx, int on);
+/* diagnostic (CAFE_GEMM_STAMPS=1 at cafe_create): per-block placement + timeline words of the last K2 launch */
+int cafe_debug_stamps(cafe_ctx* ctx, unsigned long long* out, size_t words);
 
 /* Stand-alone kernels exposed for unit parity tests and the roofline probe. */
 /* builds `count` matrices of order n for (lambda[i], t[i]) pairs with matrix_cache_key quantization
