@@ -67,9 +67,56 @@ __global__ __launch_bounds__(256) void leaf_gather_kernel(const GatherArgs a) {
     }
 }
 
+// Fast path for the common shape (one or two leaves, no error model, store mode): a thread owns two
+// adjacent families (16-byte stores, 256 threads = 4 KB contiguous per row) and kFastRows rows; the
+// gathers of all its rows are issued before the first store.
+constexpr int kFastRows = 8;
+template <int NLEAF>
+__global__ __launch_bounds__(256) void leaf_gather_fast_kernel(const GatherArgs a) {
+    const int cat = blockIdx.z;
+    const int f = (blockIdx.x * 256 + threadIdx.x) * 2;
+    if (f >= a.ld) return;
+    const int r0 = blockIdx.y * kFastRows;
+    const unsigned ldp = (unsigned)a.pool.ld;
+    double* __restrict__ dst = a.dst + (int64_t)cat * a.panel_kstride + (int64_t)r0 * a.ld + f;
+    unsigned o0[NLEAF], o1[NLEAF];
+    const double* P[NLEAF];
+#pragma unroll
+    for (int l = 0; l < NLEAF; ++l) {
+        const int32_t* cnt = a.counts + (int64_t)a.taxon[l] * a.counts_ld + a.f0 + f;
+        o0[l] = (unsigned)cnt[0];
+        o1[l] = (unsigned)cnt[1];
+        P[l] = a.pool.base + (int64_t)a.slot[l][cat] * a.pool.stride + (int64_t)(r0 + a.row_off) * ldp;
+    }
+    double2 v[kFastRows];
+#pragma unroll
+    for (int rr = 0; rr < kFastRows; ++rr) {
+        v[rr] = make_double2(0.0, 0.0);
+        if (r0 + rr < a.rows) {
+            double x = 1.0, y = 1.0;
+#pragma unroll
+            for (int l = 0; l < NLEAF; ++l) {
+                const double* row = P[l] + (unsigned)rr * ldp;
+                x *= row[o0[l]];
+                y *= row[o1[l]];
+            }
+            v[rr] = make_double2(x, y);
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < kFastRows; ++rr)
+        if (r0 + rr < a.rows_store) *reinterpret_cast<double2*>(dst + (int64_t)rr * a.ld) = v[rr];
+}
+
 hipError_t launch_leaf_gather(const GatherArgs& a, int n_categories, hipStream_t stream) {
-    dim3 grid((a.ld + 255) / 256, (a.rows_store + kGatherRows - 1) / kGatherRows, n_categories), block(256);
     (void)hipGetLastError();
+    if (a.err == nullptr && a.mode == 0 && a.n_leaf >= 1 && a.n_leaf <= 2) {
+        dim3 grid((a.ld / 2 + 255) / 256, (a.rows_store + kFastRows - 1) / kFastRows, n_categories), block(256);
+        if (a.n_leaf == 1) hipLaunchKernelGGL(leaf_gather_fast_kernel<1>, grid, block, 0, stream, a);
+        else hipLaunchKernelGGL(leaf_gather_fast_kernel<2>, grid, block, 0, stream, a);
+        return hipGetLastError();
+    }
+    dim3 grid((a.ld + 255) / 256, (a.rows_store + kGatherRows - 1) / kGatherRows, n_categories), block(256);
     hipLaunchKernelGGL(leaf_gather_kernel, grid, block, 0, stream, a);
     return hipGetLastError();
 }
