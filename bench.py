@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--lam", type=float, default=0.002)
     ap.add_argument("--alpha", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the real thing); gloo only to rehearse the N>1 path on a box with fewer GPUs than ranks")
     ap.add_argument("--cpu-matrices", type=int, default=3, help="matrices built by the O(N^3) reference algorithm in the CPU sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU sample (0 = the host CPU share)")
     ap.add_argument("--cpu-families", type=int, default=0, help="families pruned in the CPU sample (0 = 4 per host thread)")
@@ -93,10 +95,14 @@ def main():
     from cafexp_amd import capi, problem as P, synth
     from cafexp_amd.gamma_rates import discrete_gamma
 
-    torch.cuda.set_device(local_rank)
+    device = local_rank % torch.cuda.device_count()          # == local_rank on a real N-GPU launch
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     pb, _ = synth.make_problem(n_taxa=args.taxa, n_families=args.families, max_count=args.max_count)
     F = pb.n_families
@@ -108,16 +114,19 @@ def main():
         pr = P.Params(lambdas=np.array([args.lam]), prior=P.prior_uniform(pb.max_root_family_size))
     lo, hi = P.shard_families(F, world, rank)
     shard = dataclasses.replace(pb, counts=np.ascontiguousarray(pb.counts[lo:hi]), family_ids=pb.family_ids[lo:hi])
-    ctx = capi.Context(shard, max_categories=max(1, K), device=local_rank)
+    ctx = capi.Context(shard, max_categories=max(1, K), device=device)
 
     buf = torch.zeros(2, dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream()
 
     def step():
         ctx.score_partial(pr, buf.data_ptr(), stream.cuda_stream, alpha=args.alpha)
-        if world > 1:
+        if world > 1 and args.backend == "nccl":
             dist.all_reduce(buf)                      # RCCL over xGMI: {sum lnL, rejects}
-        return ctx.finish(buf.cpu().numpy())          # host read-back = the scorer's return value
+        pair = buf.cpu()                              # host read-back = the scorer's return value
+        if world > 1 and args.backend != "nccl":
+            dist.all_reduce(pair)
+        return ctx.finish(pair.numpy())
 
     def fence():
         torch.cuda.synchronize()
@@ -141,7 +150,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -150,9 +159,12 @@ def main():
         achieved = flops / (ms_gemm * 1e-3) / 1e12 if ms_gemm > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath):                     # PMC passes of this same workload (profiles/)
             try:
-                traffic = json.load(open(tpath)).get("prune_gemm_hbm_bytes_per_launch")
+                t = json.load(open(tpath))
+                if t.get("workload") == {"families": args.families, "taxa": args.taxa, "max_count": args.max_count,
+                                         "categories": args.categories, "gpus": world}:
+                    traffic = t.get("prune_gemm_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {

@@ -45,3 +45,13 @@ m = cu == c0
 o = np.argsort(t0[m])
 for i in o[:12]:
     print("cu", c0, "slot", slot[m][i], "t0 %.1f t1 %.1f t2 %.1f t3 %.1f" % tuple((x[m][i] - base) / 100.0 for x in (t0, t1, t2, t3)))
+
+# --- dispatch placement: does blockIdx.x & 7 pick the XCD?
+allw = ctx.debug_stamps(6 * nblk).reshape(-1, 6)
+gx = 8 * 49 * 5          # gridDim.x of an MI=9 launch at 50k families
+idxs = np.nonzero(allw[:, 5] > 0)[0]
+bx = idxs % gx
+xcc_id = (allw[idxs, 1].astype(np.int64)) & 0xF
+import collections
+tab = collections.Counter(zip((bx & 7).tolist(), xcc_id.tolist()))
+print("(blockIdx.x & 7, XCC_ID) -> blocks:", sorted(tab.items())[:24], "... distinct pairs", len(tab))
