@@ -222,6 +222,7 @@ public:
     virtual double infer_family_likelihoods(root_equilibrium_distribution* prior, const std::map<int, int>& root_distribution_map, const lambda* p_lambda) = 0;
     virtual std::string name() const = 0;
     virtual void write_family_likelihoods(std::ostream& ost) = 0;
+    virtual void write_vital_statistics(std::ostream& ost, double final_likelihood);     // core.cpp:96
     virtual inference_optimizer_scorer* get_lambda_optimizer(user_data& data) = 0;
     const std::vector<family_info_stash>& get_results() const { return results; }
     const event_monitor& get_monitor() const { return _monitor; }
@@ -270,6 +271,7 @@ public:
     double infer_family_likelihoods(root_equilibrium_distribution* prior, const std::map<int, int>& rootdist, const lambda* p_lambda) override;
     std::string name() const override { return "Gamma"; }
     void write_family_likelihoods(std::ostream& ost) override;
+    void write_vital_statistics(std::ostream& ost, double final_likelihood) override;   // + "Alpha:" (gamma_core.cpp:43)
     inference_optimizer_scorer* get_lambda_optimizer(user_data& data) override;
     const std::vector<std::vector<double>>& category_likelihoods() const { return _category_likelihoods; }
 };

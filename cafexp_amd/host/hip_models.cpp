@@ -195,6 +195,11 @@ double hip_gamma_model::infer_family_likelihoods(root_equilibrium_distribution* 
     return score;
 }
 
+void hip_gamma_model::write_vital_statistics(std::ostream& ost, double final_likelihood) {
+    model::write_vital_statistics(ost, final_likelihood);
+    ost << "Alpha: " << _alpha << std::endl;
+}
+
 void hip_gamma_model::write_family_likelihoods(std::ostream& ost) {
     ost << "#FamilyID\tGamma Cat Median\tLikelihood of Category\tLikelihood of Family\tPosterior Probability\tSignificant" << std::endl;
     for (const auto& r : results) ost << r << "\n";

@@ -349,6 +349,15 @@ void event_monitor::summarize(std::ostream& ost) const {
     }
 }
 
+void model::write_vital_statistics(std::ostream& ost, double final_likelihood) {
+    ost << "Model " << name() << " Final Likelihood (-lnL): " << final_likelihood << std::endl;
+    ost << "Lambda: " << _p_lambda->to_string() << std::endl;
+    if (_p_error_model) ost << "Epsilon: " << _p_error_model->get_epsilons()[0] << std::endl;
+    const std::set<double> lengths = _p_tree->get_branch_lengths();
+    ost << "Maximum possible lambda for this topology: " << 1 / *std::max_element(lengths.begin(), lengths.end()) << std::endl;
+    _monitor.summarize(ost);
+}
+
 void model::initialize_lambda(const clade* lambda_tree) {
     if (lambda_tree) {
         std::set<int> uniq;

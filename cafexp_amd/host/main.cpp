@@ -17,7 +17,7 @@ using namespace cafe;
 static void usage() {
     std::fprintf(stderr,
         "usage: cafexp_hip -t TREE -i FAMILIES [-l LAMBDA | -m L1,L2,.. -y LAMBDA_TREE | -y LAMBDA_TREE] [-k K] [-a ALPHA]\n"
-        "                  [-e [ERRMODEL]] [-p [POISSON_LAMBDA]] [-f ROOTDIST] [-z] [-s SEED] [-I MAXITER] [-d DEVICE] [--reps N] [--family-out FILE]\n");
+        "                  [-e [ERRMODEL]] [-p [POISSON_LAMBDA]] [-f ROOTDIST] [-z] [-s SEED] [-I MAXITER] [-d DEVICE] [--reps N] [--family-out FILE] [-o OUTDIR] [--limit N]\n");
 }
 
 static std::string slurp_first_line(const std::string& path) {
@@ -35,7 +35,8 @@ static void print_num(const char* key, double v, bool comma = true) {
 }
 
 int main(int argc, char** argv) {
-    std::string tree_path, fam_path, lambda_tree_path, multi, err_path, rootdist_path, family_out;
+    std::string tree_path, fam_path, lambda_tree_path, multi, err_path, rootdist_path, family_out, out_dir;
+    long limit = -1;
     double fixed_lambda = 0, fixed_alpha = -1, poisson = 0;
     int k = 1, device = 0, max_iter = 300, reps = 1;
     bool use_err = false, use_poisson = false, keep_all = false;
@@ -61,6 +62,8 @@ int main(int argc, char** argv) {
         else if (a == "-d") device = std::stoi(next());
         else if (a == "--reps") reps = std::stoi(next());
         else if (a == "--family-out") family_out = next();
+        else if (a == "-o") out_dir = next();
+        else if (a == "--limit") limit = std::stol(next());
         else { usage(); return 2; }
     }
     if (tree_path.empty() || fam_path.empty()) { usage(); return 2; }
@@ -101,6 +104,7 @@ int main(int argc, char** argv) {
             auto rem = std::remove_if(d.gene_families.begin(), d.gene_families.end(), [&](const gene_family& f) { return !f.exists_at_root(d.p_tree.get()); });
             d.gene_families.erase(rem, d.gene_families.end());
         }
+        if (limit >= 0 && (size_t)limit < d.gene_families.size()) d.gene_families.resize(limit);
         if (use_poisson && poisson > 0) d.p_prior.reset(new poisson_distribution(poisson));
         else if (use_poisson) throw std::runtime_error("-p without a value (empirical Poisson prior) is not supported by this driver");
         else d.p_prior.reset(new uniform_distribution());
@@ -147,6 +151,12 @@ int main(int argc, char** argv) {
             std::ofstream f(family_out);
             f.precision(17);
             mdl->write_family_likelihoods(f);
+        }
+        if (!out_dir.empty()) {                                  // the two files of estimator::compute (execute.cpp:49-54)
+            std::ofstream rf(out_dir + "/" + mdl->name() + "_results.txt");
+            mdl->write_vital_statistics(rf, score);
+            std::ofstream lf(out_dir + "/" + mdl->name() + "_family_likelihoods.txt");
+            mdl->write_family_likelihoods(lf);
         }
         std::printf("{\"model\": \"%s\", ", mdl->name().c_str());
         print_num("neg_lnl", score);

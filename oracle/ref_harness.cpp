@@ -214,6 +214,20 @@ static int job_score(const kv_t& kv) {
         if (mdl == "gamma") { printf(", "); parr("category_likelihood", a); printf(", "); parr("family_likelihood", b); printf(", "); parr("posterior", c); }
         else { printf(", "); parr("family_lnl", a); }
     }
+    if (geti(kv, "files", 0)) {
+        // the two files estimator::compute writes (execute.cpp:49-54), verbatim, default stream precision
+        std::ostringstream vital, fam;
+        m->write_vital_statistics(vital, score);
+        m->write_family_likelihoods(fam);
+        auto esc = [](const std::string& t) {
+            std::string o;
+            for (char ch : t) {
+                if (ch == '\n') o += "\\n"; else if (ch == '\t') o += "\\t"; else if (ch == '"') o += "\\\""; else if (ch == '\\') o += "\\\\"; else o += ch;
+            }
+            return o;
+        };
+        printf(", \"results_txt\": \"%s\", \"family_likelihoods_txt\": \"%s\"", esc(vital.str()).c_str(), esc(fam.str()).c_str());
+    }
     printf("}\n");
     return 0;
 }

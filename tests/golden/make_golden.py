@@ -129,6 +129,9 @@ def main():
         "mammals_first200_base": dict(tree=mt, families=mf, limit=200, per_family=1, **{"lambda": 0.0018}),
         "mammals_first200_gamma": dict(tree=mt, families=mf, limit=200, per_family=1, model="gamma", k=4, alpha=2.0, **{"lambda": 0.005}),
         "mammals_first200_err": dict(tree=mt, families=mf, limit=200, per_family=1, errfile=data("errormodel_0.1.txt"), **{"lambda": 0.0018}),
+        "mammals_first200_base_files": dict(tree=mt, families=mf, limit=200, files=1, **{"lambda": 0.0018}),
+        "mammals_first200_gamma_files": dict(tree=mt, families=mf, limit=200, files=1, model="gamma", k=3, alpha=2.5, **{"lambda": 0.005}),
+        "mammals_first200_err_files": dict(tree=mt, families=mf, limit=200, files=1, errfile=data("errormodel_0.1.txt"), **{"lambda": 0.0018}),
         "synth20_base": dict(tree=data("synth20_tree.txt"), families=data("synth20_families.txt"), per_family=1, **{"lambda": 0.004}),
         "synth20_gamma_k8": dict(tree=data("synth20_tree.txt"), families=data("synth20_families.txt"), per_family=1, model="gamma", k=8, alpha=2.0, **{"lambda": 0.004}),
         "synth20_multilambda_err": dict(tree=data("synth20_tree.txt"), families=data("synth20_families.txt"), per_family=1, lambdas="0.004,0.008",

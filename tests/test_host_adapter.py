@@ -76,3 +76,33 @@ def test_lambda_epsilon_search_runs():
     """`-e` without a file: default error model + lambda_epsilon_optimizer (core.cpp:39-44, base_model.cpp:133)."""
     d = _run("-t", T, "-i", F, "-e", "-s", 3, "-I", 40)
     assert math.isfinite(d["neg_lnl"]) and 0 <= d["epsilon"] < 0.5 and d["lambda"][0] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,args,model", [
+    ("mammals_first200_base_files", ["-l", 0.0018], "Base"),
+    ("mammals_first200_gamma_files", ["-l", 0.005, "-k", 3, "-a", 2.5], "Gamma"),
+    ("mammals_first200_err_files", ["-l", 0.0018, "-e", EM], "Base"),
+])
+def test_output_files_match_the_reference_writers(golden, tmp_path, name, args, model):
+    """<Model>_results.txt and <Model>_family_likelihoods.txt (estimator::compute, execute.cpp:49-54;
+    write_vital_statistics core.cpp:96; write_family_likelihoods base_model.cpp:114 / gamma_core.cpp:49) against the
+    text the compiled reference wrote for the same inputs.  Numbers are printed with the default stream precision
+    (6 significant digits), so fields must agree to a unit in the last printed digit."""
+    e = golden["scores"][name]
+    _run("-t", T, "-i", F, "--limit", 200, "-o", str(tmp_path), *args)
+    for fname, key in ((model + "_results.txt", "results_txt"), (model + "_family_likelihoods.txt", "family_likelihoods_txt")):
+        got = open(os.path.join(str(tmp_path), fname)).read().splitlines()
+        want = e[key].splitlines()
+        assert len(got) == len(want), fname
+        for g_line, w_line in zip(got, want):
+            gf, wf = g_line.split("\t"), w_line.split("\t")
+            assert len(gf) == len(wf), (g_line, w_line)
+            for a, b in zip(gf, wf):
+                if a == b:
+                    continue
+                pa, pb = a.split(), b.split()          # "Lambda:   0.005" style lines: compare token-wise
+                assert len(pa) == len(pb), (g_line, w_line)
+                for x, y in zip(pa, pb):
+                    if x != y:
+                        assert abs(float(x) - float(y)) <= 2e-5 * abs(float(y)), (g_line, w_line)
