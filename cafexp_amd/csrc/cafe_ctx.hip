@@ -388,6 +388,8 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     size_t budget = p->workspace_limit ? p->workspace_limit : (size_t)(free_b * 0.80);
     const size_t per_col = (size_t)c->n_panels * c->Kmax * c->rows_pad * sizeof(double);
     int64_t cols = (int64_t)(budget / per_col) / kBN * kBN;
+    // K2 addresses a panel category through a 32-bit buffer descriptor: rows_pad * cols * 8 bytes must stay below 4 GB
+    cols = std::min<int64_t>(cols, (int64_t)(0xFFFFFFF0ll / ((int64_t)c->rows_pad * 8)) / kBN * kBN);
     if (cols < kBN) { set_err(c, "cafe_create: %zu bytes of workspace cannot hold %d panels of one 128-family tile", budget, c->n_panels); return CAFE_ERR_MEMORY; }
     c->chunk_cols = std::min<int64_t>(cols, c->Fp);
     c->panel_kstride = (int64_t)c->rows_pad * c->chunk_cols;

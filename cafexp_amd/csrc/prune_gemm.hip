@@ -47,6 +47,7 @@ constexpr int a_stride(int bm) { return (bm % 32 == 16) ? bm : bm + 16; }
 // sibling (no error model) is folded into the epilogue.
 template <int MI, bool MUL, bool LEAF>
 __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the body uses amdgcn-only types (buffer resource); hipcc's host pass only needs the stub
     constexpr int BM = 16 * MI;
     constexpr int SA = a_stride(BM);
     constexpr int A_TILE = kBK * SA, B_TILE = kBK * kBStride;
@@ -69,7 +70,6 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
     const int row0 = row_tile * BM;                        // parent size row0 + 1 is the tile's first row
     const int col0 = col_tile * kBN;
 
-    const double* __restrict__ A = a.pool.base + (int64_t)a.slot[cat] * a.pool.stride + row0;
     const double* __restrict__ B = a.src + (int64_t)cat * a.panel_kstride + col0;
     double* __restrict__ C = a.dst + (int64_t)cat * a.panel_kstride + col0;
     const int lda = a.pool.ld;
@@ -80,11 +80,16 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
     // A: with SA == BM the [16][BM] image is contiguous, 2*MI pieces of 1 KB laid end to end (a piece may
     // span two k-rows; the per-lane source address makes that free); slot s moves pieces s, s+16, ...
     // and wraps, re-writing an identical piece rather than branching.  With a padded row (even MI) each
-    // k-row is moved on its own with the tail lanes masked off.  Source addresses are a uniform row
-    // base plus a per-lane 32-bit offset that is computed once.
+    // k-row is moved on its own with the tail lanes masked off.
     constexpr bool A_CONTIG = (SA == BM);
     constexpr int NP = 2 * MI, PER = (NP + 15) / 16;
-    unsigned a_src[4][PER > 0 ? PER : 1];
+    // Buffer addressing (buffer_load_dwordx4 ... lds): resource descriptor in SGPRs, one 32-bit per-lane
+    // byte offset that never changes, and a scalar byte offset per piece -- the DMA issue needs no VALU at all.
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.pool.base + (int64_t)a.slot[cat] * a.pool.stride), 0, (int)(a.pool.stride * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.src + (int64_t)cat * a.panel_kstride), 0, (int)(a.panel_kstride * 8 > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : a.panel_kstride * 8), 0x00020000);
+    unsigned a_voff[4][PER > 0 ? PER : 1];       // bytes
     int a_dst[4][PER > 0 ? PER : 1];
     if (A_CONTIG) {
 #pragma unroll
@@ -94,28 +99,27 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
                 int piece = q * 4 + wave + 16 * j;
                 if (piece >= NP) piece -= NP;
                 const int e = piece * 128 + lane * 2;          // element of the tile image this lane moves
-                a_src[q][j] = (unsigned)((e / BM) * lda + (e % BM));
+                a_voff[q][j] = (unsigned)(((e / BM) * lda + (e % BM) + row0) * 8);
                 a_dst[q][j] = piece * 128;
             }
     }
-    const unsigned lane2 = (unsigned)lane * 2;
+    const unsigned a_voff_row = (unsigned)((row0 + lane * 2) * 8);
+    const unsigned b_voff = (unsigned)((col0 + lane * 2) * 8);
     auto stage_quarter = [&](int k0, int buf, int q) {
         double* As = lds + buf * (A_TILE + B_TILE);
         double* Bs = As + A_TILE;
         const int krow = q * 4 + wave;
         if (A_CONTIG) {
-            const double* ga = A + (int64_t)k0 * lda;
+            const int soff = k0 * lda * 8;
 #pragma unroll
             for (int j = 0; j < PER; ++j)
-                __builtin_amdgcn_global_load_lds((gptr_t)(ga + a_src[q][j]), (lptr_t)(As + a_dst[q][j]), 16, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(As + a_dst[q][j]), 16, a_voff[q][j], soff, 0, 0);
         } else {
-            const double* ga = A + (int64_t)(k0 + krow) * lda;
             constexpr int nl = BM >= 128 ? 64 : BM / 2;
             if (nl == 64 || lane < nl)
-                __builtin_amdgcn_global_load_lds((gptr_t)(ga + lane2), (lptr_t)(As + krow * SA), 16, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(As + krow * SA), 16, a_voff_row, (k0 + krow) * lda * 8, 0, 0);
         }
-        const double* gb = B + (int64_t)(k0 + krow) * ldb;
-        __builtin_amdgcn_global_load_lds((gptr_t)(gb + lane2), (lptr_t)(Bs + krow * kBStride), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(Bs + krow * kBStride), 16, b_voff, (k0 + krow) * ldb * 8, 0, 0);
     };
 
     double4_t acc[MI][2];
@@ -270,6 +274,9 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
         o[1] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
         o[2] = st0; o[3] = st1; o[4] = st2; o[5] = st3;
     }
+#else
+    (void)a;
+#endif
 }
 
 int prune_gemm_pick_mi(int rows) {
