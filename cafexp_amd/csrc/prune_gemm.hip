@@ -96,10 +96,16 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
-                int piece = q * 4 + wave + 16 * j;
+                int piece = q * 4 + wave + 16 * j;             // scalar
                 if (piece >= NP) piece -= NP;
-                const int e = piece * 128 + lane * 2;          // element of the tile image this lane moves
-                a_voff[q][j] = (unsigned)(((e / BM) * lda + (e % BM) + row0) * 8);
+                // element e = 128*piece + 2*lane of the [16][BM] image -> (k-row, column).  128*piece splits on
+                // the scalar unit; adding 2*lane (<= 126 < 2*BM as BM >= 64) wraps at most twice: a few VALU
+                // instead of a vector div/mod
+                const int r0s = (piece * 128) / BM, c0s = (piece * 128) % BM;
+                int c = c0s + lane * 2, r = r0s;
+                if (c >= BM) { c -= BM; r += 1; }
+                if (c >= BM) { c -= BM; r += 1; }
+                a_voff[q][j] = (unsigned)((r * lda + c + row0) * 8);
                 a_dst[q][j] = piece * 128;
             }
     }
@@ -122,13 +128,6 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(Bs + krow * kBStride), 16, b_voff, (k0 + krow) * ldb * 8, 0, 0);
     };
 
-    double4_t acc[MI][2];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        acc[i][0] = double4_t{0.0, 0.0, 0.0, 0.0};
-        acc[i][1] = double4_t{0.0, 0.0, 0.0, 0.0};
-    }
-
     const int l15 = lane & 15, l4 = lane >> 4;
     const int n_k = (a.k_valid + kBK - 1) / kBK;
     const int a_off = l4 * SA + l15;
@@ -136,6 +135,12 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
 
 #pragma unroll
     for (int q = 0; q < 4; ++q) stage_quarter(0, 0, q);
+    double4_t acc[MI][2];                                  // zeroed while the first tile is in flight
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        acc[i][0] = double4_t{0.0, 0.0, 0.0, 0.0};
+        acc[i][1] = double4_t{0.0, 0.0, 0.0, 0.0};
+    }
     __syncthreads();                                       // vmcnt(0) + barrier: tile 0 has landed
     if (a.stamps) st1 = __builtin_amdgcn_s_memrealtime();
 
@@ -184,17 +189,24 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
     double* stg = lds + wave * (16 * SS);
     const int e_row = lane >> 4, e_col = (lane & 15) * 2;   // row inside a group of 4, first of two columns
     const int gcol = wave * 32 + e_col;                     // column inside the block tile
-    double* const Ct = C + (int64_t)(row0 + a.out_off) * ldb;                 // uniform: tile's first output row
-    const unsigned c_lane = (unsigned)(e_row * ldb + gcol);                    // per-lane element offset
-    const double* Lt = nullptr;                                                // leaf matrix rows of this tile
-    unsigned l_lane0 = 0, l_lane1 = 0;
+    typedef int int4_t __attribute__((ext_vector_type(4)));
+    typedef int int2_t __attribute__((ext_vector_type(2)));
+    const int kbytes = (int)(a.panel_kstride * 8 > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : a.panel_kstride * 8);
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dst + (int64_t)cat * a.panel_kstride), 0, kbytes, 0x00020000);
+    const unsigned c_voff = (unsigned)((e_row * ldb + col0 + gcol) * 8);       // per-lane byte offset, fixed
+    const int c_soff0 = (row0 + a.out_off) * ldb * 8;                          // scalar: tile's first output row
+    const int ldl = a.lpool.ld;
+    __amdgpu_buffer_rsrc_t rsL = rsC;
+    unsigned l_voff0 = 0, l_voff1 = 0;
+    int l_soff0 = 0;
     if (LEAF) {
         const int32_t* cnt = a.counts + (int64_t)a.taxon[0] * a.counts_ld + a.f0 + col0 + gcol;
-        Lt = a.lpool.base + (int64_t)a.leaf_slot[0][cat] * a.lpool.stride + (int64_t)(row0 + 1) * a.lpool.ld;   // parent size row0+1
-        l_lane0 = (unsigned)(e_row * a.lpool.ld + cnt[0]);
-        l_lane1 = (unsigned)(e_row * a.lpool.ld + cnt[1]);
+        rsL = __builtin_amdgcn_make_buffer_rsrc((void*)(a.lpool.base + (int64_t)a.leaf_slot[0][cat] * a.lpool.stride), 0,
+                                                (int)(a.lpool.stride * 8), 0x00020000);
+        l_voff0 = (unsigned)((e_row * ldl + cnt[0]) * 8);
+        l_voff1 = (unsigned)((e_row * ldl + cnt[1]) * 8);
+        l_soff0 = (row0 + 1) * ldl * 8;                                        // parent size row0 + 1
     }
-    const int ldl = a.lpool.ld;
     const int rows_here = a.rows - row0;                    // valid rows of this tile (>= BM for interior tiles)
     struct Pre { double2 f[4]; };
     // FULL: the tile has all BM rows (always true when 16*MI divides the row count): no per-row masks
@@ -205,12 +217,11 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
             double2 f = make_double2(1.0, 1.0);
             if (decltype(full)::value || step + e_row < rows_here) {
                 if (LEAF) {
-                    const double* lr = Lt + (int64_t)step * ldl;
-                    f.x = lr[l_lane0];
-                    f.y = lr[l_lane1];
+                    f.x = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsL, l_voff0, l_soff0 + step * ldl * 8, 0));
+                    f.y = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsL, l_voff1, l_soff0 + step * ldl * 8, 0));
                 }
                 if (MUL) {
-                    const double2 old = *reinterpret_cast<const double2*>(Ct + (int64_t)step * ldb + c_lane);
+                    const double2 old = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rsC, c_voff, c_soff0 + step * ldb * 8, 0));
                     f.x *= old.x;
                     f.y *= old.y;
                 }
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
                     v.x *= p.f[q].x;
                     v.y *= p.f[q].y;
                 }
-                *reinterpret_cast<double2*>(Ct + (int64_t)step * ldb + c_lane) = v;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(int4_t, v), rsC, c_voff, c_soff0 + step * ldb * 8, 0);
             }
         }
     };
