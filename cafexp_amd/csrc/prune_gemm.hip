@@ -50,45 +50,31 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the body uses amdgcn-only types (buffer resource); hipcc's host pass only needs the stub
     constexpr int BM = 16 * MI;
     constexpr int SA = a_stride(BM);
-    constexpr int A_TILE = kBK * SA, B_TILE = kBK * kBStride;
-    __shared__ double lds[2 * (A_TILE + B_TILE)];
+    constexpr int A_TILE = kBK * SA, B_TILE = kBK * kBStride, STAGE = A_TILE + B_TILE;
+    __shared__ double lds[2 * STAGE];
+    typedef int int4_t __attribute__((ext_vector_type(4)));
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: LDS-DMA bases (M0) need no VALU
-    const int cat = blockIdx.z;
-    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int lda = a.pool.ld, ldb = a.ld, ldl = a.lpool.ld;
+    unsigned long long st0 = 0;
     if (a.stamps) st0 = __builtin_amdgcn_s_memrealtime();
 
-    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch, a speed-only
-    // assumption), so XCD x takes the column tiles x, x+8, ... and runs their row tiles back to back:
-    // the row tiles of one column tile then share the child panel (B) in that XCD's L2.
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int row_tile = idx % a.n_row_tiles;
-    const int col_tile = xcd + 8 * (idx / a.n_row_tiles);
-    if (col_tile >= a.n_col_tiles) return;
-    const int row0 = row_tile * BM;                        // parent size row0 + 1 is the tile's first row
-    const int col0 = col_tile * kBN;
+    // ---- persistent tile loop.  The grid is 2 workgroups per CU; a workgroup walks a fixed list of output
+    // tiles so that the first K tile of the next output tile is already being fetched while the current one
+    // is finished and stored: no per-tile launch gap or cold prologue.  XCD-aware order (speed only): blocks
+    // b and b+8 share an XCD under round-robin dispatch, so XCD x owns the column tiles x, x+8, ... of every
+    // category and its 64 blocks take consecutive (category, column tile, row tile) triples, row tile
+    // fastest: the row tiles of one column tile run together and share the child panel (B) in that L2.
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, n_local_blocks = gridDim.x >> 3;
+    const int my_cols = (a.n_col_tiles - xcd + 7) >> 3;                      // column tiles owned by this XCD
+    const int n_tiles = a.n_categories * my_cols * a.n_row_tiles;
 
-    const double* __restrict__ B = a.src + (int64_t)cat * a.panel_kstride + col0;
-    double* __restrict__ C = a.dst + (int64_t)cat * a.panel_kstride + col0;
-    const int lda = a.pool.ld;
-    const int ldb = a.ld;
-
-    // LDS-DMA fill of one tile pair, issued in four quarters (one per k-step) so that the issue slots
-    // fall in the shadow of the MFMAs.  16 slots = 4 quarters x 4 waves.  B: k-row `slot` is one 1 KB piece.
-    // A: with SA == BM the [16][BM] image is contiguous, 2*MI pieces of 1 KB laid end to end (a piece may
-    // span two k-rows; the per-lane source address makes that free); slot s moves pieces s, s+16, ...
-    // and wraps, re-writing an identical piece rather than branching.  With a padded row (even MI) each
-    // k-row is moved on its own with the tail lanes masked off.
+    // per-lane constants that do not depend on the tile (tile origins travel in the scalar offsets)
     constexpr bool A_CONTIG = (SA == BM);
     constexpr int NP = 2 * MI, PER = (NP + 15) / 16;
-    // Buffer addressing (buffer_load_dwordx4 ... lds): resource descriptor in SGPRs, one 32-bit per-lane
-    // byte offset that never changes, and a scalar byte offset per piece -- the DMA issue needs no VALU at all.
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.pool.base + (int64_t)a.slot[cat] * a.pool.stride), 0, (int)(a.pool.stride * 8), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.src + (int64_t)cat * a.panel_kstride), 0, (int)(a.panel_kstride * 8 > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : a.panel_kstride * 8), 0x00020000);
     unsigned a_voff[4][PER > 0 ? PER : 1];       // bytes
     int a_dst[4][PER > 0 ? PER : 1];
     if (A_CONTIG) {
@@ -99,191 +85,217 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
                 int piece = q * 4 + wave + 16 * j;             // scalar
                 if (piece >= NP) piece -= NP;
                 // element e = 128*piece + 2*lane of the [16][BM] image -> (k-row, column).  128*piece splits on
-                // the scalar unit; adding 2*lane (<= 126 < 2*BM as BM >= 64) wraps at most twice: a few VALU
-                // instead of a vector div/mod
+                // the scalar unit; adding 2*lane (<= 126 < 2*BM as BM >= 64) wraps at most twice
                 const int r0s = (piece * 128) / BM, c0s = (piece * 128) % BM;
                 int c = c0s + lane * 2, r = r0s;
                 if (c >= BM) { c -= BM; r += 1; }
                 if (c >= BM) { c -= BM; r += 1; }
-                a_voff[q][j] = (unsigned)((r * lda + c + row0) * 8);
+                a_voff[q][j] = (unsigned)((r * lda + c) * 8);
                 a_dst[q][j] = piece * 128;
             }
     }
-    const unsigned a_voff_row = (unsigned)((row0 + lane * 2) * 8);
-    const unsigned b_voff = (unsigned)((col0 + lane * 2) * 8);
-    auto stage_quarter = [&](int k0, int buf, int q) {
-        double* As = lds + buf * (A_TILE + B_TILE);
+    const unsigned lane16 = (unsigned)(lane * 16);
+    const int a_off = l4 * SA + l15;
+    const int b_off = A_TILE + l4 * kBStride + wave * 32 + l15;
+    const int n_k = (a.k_valid + kBK - 1) / kBK;
+    const int last_steps = (a.k_valid - (n_k - 1) * kBK + 3) / 4;
+    const int kbytes = (int)(a.panel_kstride * 8 > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : a.panel_kstride * 8);
+    constexpr int SS = 34;                                  // epilogue staging row stride (doubles)
+    const int e_row = lane >> 4, e_col = (lane & 15) * 2;   // epilogue: row inside a group of 4, first of two columns
+    const int gcol = wave * 32 + e_col;
+
+    // Tile descriptor (all scalar): buffer resources of the A matrix / child panel / parent panel and origins
+    struct Tile {
+        __amdgpu_buffer_rsrc_t rsA, rsB, rsC;
+        int cat, row0, col0, row_tile;
+    };
+    auto decode = [&](int t) -> Tile {
+        Tile x;
+        x.row_tile = t % a.n_row_tiles;
+        const int rest = t / a.n_row_tiles;
+        const int ct = xcd + 8 * (rest % my_cols);
+        x.cat = rest / my_cols;
+        x.row0 = x.row_tile * BM;
+        x.col0 = ct * kBN;
+        x.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.pool.base + (int64_t)a.slot[x.cat] * a.pool.stride), 0, (int)(a.pool.stride * 8), 0x00020000);
+        x.rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src + (int64_t)x.cat * a.panel_kstride), 0, kbytes, 0x00020000);
+        x.rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dst + (int64_t)x.cat * a.panel_kstride), 0, kbytes, 0x00020000);
+        return x;
+    };
+    // LDS-DMA fill of K tile k0 of output tile x into stage `buf`, quarter q (16 slots = 4 quarters x 4 waves).
+    // B: k-row `slot` is one 1 KB piece.  A: with SA == BM the [16][BM] image is contiguous, 2*MI pieces of 1 KB
+    // laid end to end (a piece may span two k-rows); slot s moves pieces s, s+16, ... and wraps, re-writing an
+    // identical piece rather than branching.  With a padded row (even MI) each k-row is moved on its own with
+    // the tail lanes masked off.  buffer_load ... lds: descriptor + scalar offset + fixed lane offset, no VALU.
+    auto stage_quarter = [&](const Tile& x, int k0, int buf, int q) {
+        double* As = lds + buf * STAGE;
         double* Bs = As + A_TILE;
         const int krow = q * 4 + wave;
         if (A_CONTIG) {
-            const int soff = k0 * lda * 8;
+            const int soff = (k0 * lda + x.row0) * 8;
 #pragma unroll
             for (int j = 0; j < PER; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(As + a_dst[q][j]), 16, a_voff[q][j], soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x.rsA, (lptr_t)(As + a_dst[q][j]), 16, a_voff[q][j], soff, 0, 0);
         } else {
             constexpr int nl = BM >= 128 ? 64 : BM / 2;
             if (nl == 64 || lane < nl)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(As + krow * SA), 16, a_voff_row, (k0 + krow) * lda * 8, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x.rsA, (lptr_t)(As + krow * SA), 16, lane16, ((k0 + krow) * lda + x.row0) * 8, 0, 0);
         }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(Bs + krow * kBStride), 16, b_voff, (k0 + krow) * ldb * 8, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x.rsB, (lptr_t)(Bs + krow * kBStride), 16, lane16, ((k0 + krow) * ldb + x.col0) * 8, 0, 0);
     };
 
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const int n_k = (a.k_valid + kBK - 1) / kBK;
-    const int a_off = l4 * SA + l15;
-    const int b_off = A_TILE + l4 * kBStride + wave * 32 + l15;
+    if (local >= n_tiles) return;
+    Tile cur = decode(local);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) stage_quarter(cur, 0, 0, q);
+    int g = 0;                                              // running K-tile count: stage parity
+    __syncthreads();                                        // vmcnt(0) + barrier: the first K tile has landed (later
+                                                            // ones land behind the barrier that ends each K tile)
 
-#pragma unroll
-    for (int q = 0; q < 4; ++q) stage_quarter(0, 0, q);
-    double4_t acc[MI][2];                                  // zeroed while the first tile is in flight
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        acc[i][0] = double4_t{0.0, 0.0, 0.0, 0.0};
-        acc[i][1] = double4_t{0.0, 0.0, 0.0, 0.0};
-    }
-    __syncthreads();                                       // vmcnt(0) + barrier: tile 0 has landed
-    if (a.stamps) st1 = __builtin_amdgcn_s_memrealtime();
+    for (int t = local; t < n_tiles; t += n_local_blocks) {
+        const bool has_next = t + n_local_blocks < n_tiles;
+        Tile nxt = cur;
+        if (has_next) nxt = decode(t + n_local_blocks);
 
-    // One K tile (rows c > M of the k-major matrix are zero, so padded k inside a step adds exact zeros;
-    // whole padded k-steps of the last tile are skipped).  Before the MFMAs of step s are issued, the DMA quarter of
-    // the next tile and the fragment reads of step s+1 (second register set) are already in flight, so a
-    // workgroup that has the SIMD to itself (its partner in prologue/epilogue) does not expose the LDS
-    // latency four times per tile.
-    double af[2][MI], bf[2][2];
-    auto load_frags = [&](const double* base, int s4, int set) {
+        double4_t acc[MI][2];                               // zeroed while the first K tile is in flight
 #pragma unroll
-        for (int i = 0; i < MI; ++i) af[set][i] = base[a_off + s4 * 4 * SA + i * 16];
-        bf[set][0] = base[b_off + s4 * 4 * kBStride];
-        bf[set][1] = base[b_off + s4 * 4 * kBStride + 16];
-    };
-    auto tile = [&](int kt, auto stage_next, int n_steps) {
-        const int buf = kt & 1;
-        const double* cur = lds + buf * (A_TILE + B_TILE);
-        load_frags(cur, 0, 0);
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            if (!decltype(stage_next)::value && s4 >= n_steps) break;      // last tile: skip all-padding k-steps
-            if (decltype(stage_next)::value) stage_quarter((kt + 1) * kBK, buf ^ 1, s4);
-            if (s4 < 3) load_frags(cur, s4 + 1, (s4 + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s4 & 1][i], bf[s4 & 1][0], acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s4 & 1][i], bf[s4 & 1][1], acc[i][1], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();                                   // next tile landed, this one fully read
-    };
-    for (int kt = 0; kt + 1 < n_k; ++kt) tile(kt, std::true_type{}, 4);
-    tile(n_k - 1, std::false_type{}, (a.k_valid - (n_k - 1) * kBK + 3) / 4);
-    if (a.stamps) st2 = __builtin_amdgcn_s_memrealtime();
-
-    // ---- epilogue.  C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg,
-    // i.e. a lane holds single columns.  Each 16-row block of the wave's 16*MI x 32 sub-tile goes through a
-    // small private LDS image so that a lane then owns two adjacent columns of one row: stores (and the
-    // loads of the multiply mode) are 16 B per lane, 256 B contiguous per row.  All addresses are
-    // `uniform base + per-lane 32-bit offset`; the old panel values (MUL) and the leaf factor (LEAF) of
-    // row block i+1 are loaded before block i is staged and stored.
-    constexpr int SS = 34;                                  // staging row stride (doubles)
-    double* stg = lds + wave * (16 * SS);
-    const int e_row = lane >> 4, e_col = (lane & 15) * 2;   // row inside a group of 4, first of two columns
-    const int gcol = wave * 32 + e_col;                     // column inside the block tile
-    typedef int int4_t __attribute__((ext_vector_type(4)));
-    typedef int int2_t __attribute__((ext_vector_type(2)));
-    const int kbytes = (int)(a.panel_kstride * 8 > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : a.panel_kstride * 8);
-    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dst + (int64_t)cat * a.panel_kstride), 0, kbytes, 0x00020000);
-    const unsigned c_voff = (unsigned)((e_row * ldb + col0 + gcol) * 8);       // per-lane byte offset, fixed
-    const int c_soff0 = (row0 + a.out_off) * ldb * 8;                          // scalar: tile's first output row
-    const int ldl = a.lpool.ld;
-    __amdgpu_buffer_rsrc_t rsL = rsC;
-    unsigned l_voff0 = 0, l_voff1 = 0;
-    int l_soff0 = 0;
-    if (LEAF) {
-        const int32_t* cnt = a.counts + (int64_t)a.taxon[0] * a.counts_ld + a.f0 + col0 + gcol;
-        rsL = __builtin_amdgcn_make_buffer_rsrc((void*)(a.lpool.base + (int64_t)a.leaf_slot[0][cat] * a.lpool.stride), 0,
-                                                (int)(a.lpool.stride * 8), 0x00020000);
-        l_voff0 = (unsigned)((e_row * ldl + cnt[0]) * 8);
-        l_voff1 = (unsigned)((e_row * ldl + cnt[1]) * 8);
-        l_soff0 = (row0 + 1) * ldl * 8;                                        // parent size row0 + 1
-    }
-    const int rows_here = a.rows - row0;                    // valid rows of this tile (>= BM for interior tiles)
-    struct Pre { double2 f[4]; };
-    // FULL: the tile has all BM rows (always true when 16*MI divides the row count): no per-row masks
-    auto prefetch = [&](int i, Pre& p, auto full) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int step = i * 16 + q * 4;                // uniform
-            double2 f = make_double2(1.0, 1.0);
-            if (decltype(full)::value || step + e_row < rows_here) {
-                if (LEAF) {
-                    f.x = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsL, l_voff0, l_soff0 + step * ldl * 8, 0));
-                    f.y = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsL, l_voff1, l_soff0 + step * ldl * 8, 0));
-                }
-                if (MUL) {
-                    const double2 old = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rsC, c_voff, c_soff0 + step * ldb * 8, 0));
-                    f.x *= old.x;
-                    f.y *= old.y;
-                }
-            }
-            p.f[q] = f;
-        }
-    };
-    auto flush = [&](int i, const Pre& p, auto full) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) stg[(l4 + 4 * r) * SS + j * 16 + l15] = acc[i][j][r];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            double2 v = *reinterpret_cast<const double2*>(&stg[(q * 4 + e_row) * SS + e_col]);
-            const int step = i * 16 + q * 4;
-            if (decltype(full)::value || step + e_row < rows_here) {
-                if (MUL || LEAF) {
-                    v.x *= p.f[q].x;
-                    v.y *= p.f[q].y;
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(int4_t, v), rsC, c_voff, c_soff0 + step * ldb * 8, 0);
-            }
-        }
-    };
-    auto epilogue = [&](auto full) {
-        Pre pre[2];
-        if (MUL || LEAF) prefetch(0, pre[0], full);
-        // full unroll is mandatory: a runtime i would index the accumulator array dynamically and demote
-        // it to scratch memory
-#pragma clang loop unroll(full)
         for (int i = 0; i < MI; ++i) {
-            if ((MUL || LEAF) && i + 1 < MI) prefetch(i + 1, pre[(i + 1) & 1], full);
-            flush(i, pre[i & 1], full);
+            acc[i][0] = double4_t{0.0, 0.0, 0.0, 0.0};
+            acc[i][1] = double4_t{0.0, 0.0, 0.0, 0.0};
         }
-    };
-    if (rows_here >= BM) epilogue(std::true_type{});
-    else epilogue(std::false_type{});
-    // parent size 0 only reaches child size 0 (P[0][c] = delta(c,0)): that panel row is the child's row 0,
-    // times the leaf sibling's P_leaf[0][x] = delta(x,0)
-    if (a.out_off == 1 && row_tile == 0 && tid < kBN / 2) {
-        const int c2 = tid * 2;
-        double2 v = *reinterpret_cast<const double2*>(B + c2);
+
+        // One K tile (rows c > M of the k-major matrix are zero, so padded k inside a step adds exact zeros;
+        // whole padded k-steps of the last tile are skipped).  A DMA quarter of the following K tile is issued
+        // ahead of the MFMAs of every step.  (A second fragment register set, prefetching step s+1, measured
+        // worth nothing -- the co-resident workgroup covers the LDS latency -- and costs 22 VGPRs.)
+        auto ktile = [&](const Tile& sx, int sk0, bool do_stage, int n_steps) {
+            const int buf = g & 1;
+            const double* base = lds + buf * STAGE;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                if (do_stage) stage_quarter(sx, sk0, buf ^ 1, s4);
+                if (s4 < n_steps) {
+                    double af[MI], bf[2];
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) af[i] = base[a_off + s4 * 4 * SA + i * 16];
+                    bf[0] = base[b_off + s4 * 4 * kBStride];
+                    bf[1] = base[b_off + s4 * 4 * kBStride + 16];
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[0], acc[i][0], 0, 0, 0);
+                        acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[1], acc[i][1], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();                                // the staged tile landed, this one fully read
+            ++g;
+        };
+        for (int kt = 0; kt + 1 < n_k; ++kt) ktile(cur, (kt + 1) * kBK, true, 4);
+        ktile(nxt, 0, has_next, last_steps);               // the next output tile's first K tile rides along
+
+        // ---- epilogue.  C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg, i.e.
+        // a lane holds single columns.  Each 16-row block of the wave's 16*MI x 32 sub-tile goes through a small
+        // private LDS image (in the stage that was consumed last; the other one holds the prefetched tile) so
+        // that a lane owns two adjacent columns of one row: 16-byte accesses, 256 B contiguous per row.  All
+        // accesses are buffer operations (descriptor + scalar row offset + fixed lane offset); the old panel
+        // values (MUL) and the leaf factor (LEAF) of row block i+1 are loaded before block i is stored.
+        double* stg = lds + ((g - 1) & 1) * STAGE + wave * (16 * SS);
+        const unsigned c_voff = (unsigned)((e_row * ldb + gcol) * 8);
+        const int c_soff0 = ((cur.row0 + a.out_off) * ldb + cur.col0) * 8;
+        __amdgpu_buffer_rsrc_t rsL = cur.rsC;
+        unsigned l_voff0 = 0, l_voff1 = 0;
+        int l_soff0 = 0;
         if (LEAF) {
-            const int32_t* cnt = a.counts + (int64_t)a.taxon[0] * a.counts_ld + a.f0 + col0 + c2;
-            v.x = cnt[0] == 0 ? v.x : 0.0;
-            v.y = cnt[1] == 0 ? v.y : 0.0;
+            const int32_t* cnt = a.counts + (int64_t)a.taxon[0] * a.counts_ld + a.f0 + cur.col0 + gcol;
+            rsL = __builtin_amdgcn_make_buffer_rsrc((void*)(a.lpool.base + (int64_t)a.leaf_slot[0][cur.cat] * a.lpool.stride), 0,
+                                                    (int)(a.lpool.stride * 8), 0x00020000);
+            l_voff0 = (unsigned)((e_row * ldl + cnt[0]) * 8);
+            l_voff1 = (unsigned)((e_row * ldl + cnt[1]) * 8);
+            l_soff0 = (cur.row0 + 1) * ldl * 8;             // parent size row0 + 1
         }
-        double2* dst = reinterpret_cast<double2*>(C + c2);
-        if (MUL) {
-            const double2 old = *dst;
-            v.x *= old.x;
-            v.y *= old.y;
+        const int rows_here = a.rows - cur.row0;            // valid rows of this tile (>= BM for interior tiles)
+        struct Pre { double2 f[4]; };
+        // FULL: the tile has all BM rows (always true when 16*MI divides the row count): no per-row masks
+        auto prefetch = [&](int i, Pre& p, auto full) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int step = i * 16 + q * 4;            // uniform
+                double2 f = make_double2(1.0, 1.0);
+                if (decltype(full)::value || step + e_row < rows_here) {
+                    if (LEAF) {
+                        f.x = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsL, l_voff0, l_soff0 + step * ldl * 8, 0));
+                        f.y = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsL, l_voff1, l_soff0 + step * ldl * 8, 0));
+                    }
+                    if (MUL) {
+                        const double2 old = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(cur.rsC, c_voff, c_soff0 + step * ldb * 8, 0));
+                        f.x *= old.x;
+                        f.y *= old.y;
+                    }
+                }
+                p.f[q] = f;
+            }
+        };
+        auto flush = [&](int i, const Pre& p, auto full) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stg[(l4 + 4 * r) * SS + j * 16 + l15] = acc[i][j][r];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double2 v = *reinterpret_cast<const double2*>(&stg[(q * 4 + e_row) * SS + e_col]);
+                const int step = i * 16 + q * 4;
+                if (decltype(full)::value || step + e_row < rows_here) {
+                    if (MUL || LEAF) {
+                        v.x *= p.f[q].x;
+                        v.y *= p.f[q].y;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(int4_t, v), cur.rsC, c_voff, c_soff0 + step * ldb * 8, 0);
+                }
+            }
+        };
+        auto epilogue = [&](auto full) {
+            Pre pre[2];
+            if (MUL || LEAF) prefetch(0, pre[0], full);
+            // full unroll is mandatory: a runtime i would index the accumulator array dynamically and demote
+            // it to scratch memory
+#pragma clang loop unroll(full)
+            for (int i = 0; i < MI; ++i) {
+                if ((MUL || LEAF) && i + 1 < MI) prefetch(i + 1, pre[(i + 1) & 1], full);
+                flush(i, pre[i & 1], full);
+            }
+        };
+        if (rows_here >= BM) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
+        // parent size 0 only reaches child size 0 (P[0][c] = delta(c,0)): that panel row is the child's row 0,
+        // times the leaf sibling's P_leaf[0][x] = delta(x,0)
+        if (a.out_off == 1 && cur.row_tile == 0 && tid < kBN / 2) {
+            const int c2 = tid * 2;
+            const double* Bp = a.src + (int64_t)cur.cat * a.panel_kstride + cur.col0 + c2;
+            double2 v = *reinterpret_cast<const double2*>(Bp);
+            if (LEAF) {
+                const int32_t* cnt = a.counts + (int64_t)a.taxon[0] * a.counts_ld + a.f0 + cur.col0 + c2;
+                v.x = cnt[0] == 0 ? v.x : 0.0;
+                v.y = cnt[1] == 0 ? v.y : 0.0;
+            }
+            double2* dst = reinterpret_cast<double2*>(a.dst + (int64_t)cur.cat * a.panel_kstride + cur.col0 + c2);
+            if (MUL) {
+                const double2 old = *dst;
+                v.x *= old.x;
+                v.y *= old.y;
+            }
+            *dst = v;
         }
-        *dst = v;
+        // every wave is done with the staging image before the next tile's DMA may overwrite that stage; the
+        // stores need no wait here (they drain during the next main loop)
+        __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0) only
+        __builtin_amdgcn_s_barrier();
+        cur = nxt;
     }
-    if (a.stamps && tid == 0) {             // diagnostic build only: per-block timeline (100 MHz ticks) + placement
-        const unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
-        unsigned long long* o = a.stamps + 6 * ((size_t)blockIdx.z * gridDim.x + blockIdx.x);
+    if (a.stamps && tid == 0) {             // diagnostic build only: per-block placement + lifetime (100 MHz ticks)
+        unsigned long long* o = a.stamps + 6 * (size_t)blockIdx.x;
         o[0] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
         o[1] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
-        o[2] = st0; o[3] = st1; o[4] = st2; o[5] = st3;
+        o[2] = st0; o[3] = st0; o[4] = st0; o[5] = __builtin_amdgcn_s_memrealtime();
     }
 #else
     (void)a;
@@ -312,9 +324,23 @@ static void launch_mi(const GemmArgs& a, dim3 grid, hipStream_t stream) {
     }
 }
 
-hipError_t launch_prune_gemm(const GemmArgs& a, int n_categories, hipStream_t stream) {
-    if (a.n_leaf > 1 || (a.n_leaf == 1 && a.err != nullptr)) return hipErrorInvalidValue;   // the schedule never asks for it
-    dim3 grid(8 * ((a.n_col_tiles + 7) / 8) * a.n_row_tiles, 1, n_categories);
+hipError_t launch_prune_gemm(const GemmArgs& a_in, int n_categories, hipStream_t stream) {
+    if (a_in.n_leaf > 1 || (a_in.n_leaf == 1 && a_in.err != nullptr)) return hipErrorInvalidValue;   // the schedule never asks for it
+    GemmArgs a = a_in;
+    a.n_categories = n_categories;
+    // persistent grid: two workgroups per CU (what the register/LDS budget admits), a multiple of 8 so that every
+    // XCD gets the same number; fewer when the launch has fewer tiles
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        n_cu = prop.multiProcessorCount;
+    }
+    const int64_t tiles = (int64_t)n_categories * a.n_col_tiles * a.n_row_tiles;
+    int blocks = 2 * n_cu / 8 * 8;
+    if (tiles < blocks) blocks = (int)((tiles + 7) / 8 * 8);
+    dim3 grid(blocks, 1, 1);
     (void)hipGetLastError();
     switch (a.mi) {
         case 4: launch_mi<4>(a, grid, stream); break;
