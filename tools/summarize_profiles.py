@@ -1,0 +1,89 @@
+"""Turn raw rocprofv3 output directories (under gpurun_out/) into the summaries kept in profiles/.
+
+  python tools/summarize_profiles.py stats   gpurun_out/prof   profiles/r01_bench_kernel_stats.csv
+  python tools/summarize_profiles.py traffic gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/pmc_traffic.json
+  python tools/summarize_profiles.py sq      gpurun_out/pmc_sq  profiles/r01_pmc_sq_per_launch.json
+
+Only the bench process (the one that launched prune_gemm_kernel) is kept.
+HBM counters follow /opt/skills/guides/MI355X_MICROARCH.md: separate --pmc passes, unit KB (FETCH_SIZE /
+WRITE_SIZE), gfx950 correction: FETCH_SIZE under-reports a 16 B/lane coalesced stream by 2x -> doubled.
+"""
+import csv, glob, json, os, re, shutil, sys, collections
+
+
+def short(name):
+    name = re.sub(r"\(.*$", "", name)
+    name = re.sub(r"^void ", "", name)
+    return name
+
+
+def find(dirname, suffix):
+    hits = []
+    for f in glob.glob(os.path.join(dirname, "**", "*" + suffix), recursive=True):
+        with open(f, newline="") as fh:
+            if "prune_gemm_kernel" in fh.read():
+                hits.append(f)
+    if not hits:
+        raise SystemExit("no %s with prune_gemm_kernel under %s" % (suffix, dirname))
+    return max(hits, key=os.path.getsize)
+
+
+def counters(dirname):
+    """{counter: {kernel (template args dropped): [values per dispatch]}}"""
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    with open(find(dirname, "counter_collection.csv"), newline="") as fh:
+        for row in csv.DictReader(fh):
+            k = short(row["Kernel_Name"])
+            if not k.startswith("cafe::"):
+                continue
+            if "prune_gemm_kernel" in k:
+                k = "cafe::prune_gemm_kernel"
+            out[row["Counter_Name"]][k].append(float(row["Counter_Value"]))
+    return out
+
+
+def per_launch(vals):
+    return {k: {"launches": len(v), "avg_per_launch": sum(v) / len(v)} for k, v in vals.items()}
+
+
+def main():
+    mode = sys.argv[1]
+    if mode == "stats":
+        shutil.copyfile(find(sys.argv[2], "kernel_stats.csv"), sys.argv[3])
+    elif mode == "traffic":
+        fetch = counters(sys.argv[2])["FETCH_SIZE"]
+        write = counters(sys.argv[3])["WRITE_SIZE"]
+        # bench.py's default workload (BASELINE.json configs[4]); bench.py only reports `traffic` when its own
+        # arguments match this key
+        workload = {"families": 50000, "taxa": 100, "max_count": 600, "categories": 8, "gpus": 1}
+        g = "cafe::prune_gemm_kernel"
+        f_b = 2.0 * 1024.0 * sum(fetch[g]) / len(fetch[g])
+        w_b = 1024.0 * sum(write[g]) / len(write[g])
+        doc = {
+            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over "
+                      "`python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline`; tools/summarize_profiles.py",
+            "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of a 16 B/lane coalesced stream "
+                          "(MI355X_MICROARCH.md, HBM) -> doubled; WRITE_SIZE exact; unit KB",
+            "raw": {"FETCH_SIZE_KB": per_launch(fetch), "WRITE_SIZE_KB": per_launch(write)},
+            "prune_gemm_hbm_bytes_per_launch": f_b + w_b,
+            "prune_gemm_fetch_bytes_per_launch_corrected": f_b,
+            "prune_gemm_write_bytes_per_launch": w_b,
+            "workload": workload,
+            "note": "FETCH_SIZE counts every L2 miss, Infinity-Cache hits included: the k-major matrices (34 MB) "
+                    "are re-read by workgroups whose phases differ and are served on-die; HBM proper sees the "
+                    "panels once (child panel read, parent panel written, + read in multiply mode).",
+        }
+        with open(sys.argv[4], "w") as fh:
+            json.dump(doc, fh, indent=1)
+    elif mode == "sq":
+        c = counters(sys.argv[2])
+        doc = {"source": "rocprofv3 --pmc <SQ counters> over `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline`",
+               "per_launch": {name: per_launch(v) for name, v in c.items()}}
+        with open(sys.argv[3], "w") as fh:
+            json.dump(doc, fh, indent=1)
+    else:
+        raise SystemExit(__doc__)
+
+
+if __name__ == "__main__":
+    main()
