@@ -65,12 +65,13 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
     // ---- persistent tile loop.  The grid is 2 workgroups per CU; a workgroup walks a fixed list of output
     // tiles so that the first K tile of the next output tile is already being fetched while the current one
     // is finished and stored: no per-tile launch gap or cold prologue.  XCD-aware order (speed only): blocks
-    // b and b+8 share an XCD under round-robin dispatch, so XCD x owns the column tiles x, x+8, ... of every
-    // category and its 64 blocks take consecutive (category, column tile, row tile) triples, row tile
-    // fastest: the row tiles of one column tile run together and share the child panel (B) in that L2.
+    // b and b+8 share an XCD under round-robin dispatch, so XCD x owns the (category, column tile) pairs
+    // x, x+8, ... (balanced to within one pair whatever the shard size) and its 64 blocks take consecutive
+    // (pair, row tile) couples, row tile fastest: the row tiles of one column tile run together and share the
+    // child panel (B) in that L2.
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, n_local_blocks = gridDim.x >> 3;
-    const int my_cols = (a.n_col_tiles - xcd + 7) >> 3;                      // column tiles owned by this XCD
-    const int n_tiles = a.n_categories * my_cols * a.n_row_tiles;
+    const int my_pairs = (a.n_categories * a.n_col_tiles - xcd + 7) >> 3;    // pairs owned by this XCD
+    const int n_tiles = my_pairs * a.n_row_tiles;
 
     // per-lane constants that do not depend on the tile (tile origins travel in the scalar offsets)
     constexpr bool A_CONTIG = (SA == BM);
@@ -112,9 +113,9 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
     auto decode = [&](int t) -> Tile {
         Tile x;
         x.row_tile = t % a.n_row_tiles;
-        const int rest = t / a.n_row_tiles;
-        const int ct = xcd + 8 * (rest % my_cols);
-        x.cat = rest / my_cols;
+        const int pair = xcd + 8 * (t / a.n_row_tiles);
+        const int ct = pair % a.n_col_tiles;
+        x.cat = pair / a.n_col_tiles;
         x.row0 = x.row_tile * BM;
         x.col0 = ct * kBN;
         x.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.pool.base + (int64_t)a.slot[x.cat] * a.pool.stride), 0, (int)(a.pool.stride * 8), 0x00020000);
