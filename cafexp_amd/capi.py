@@ -63,6 +63,7 @@ EXPORTS = [
     "cafe_abi_version", "cafe_create", "cafe_destroy", "cafe_last_error", "cafe_score", "cafe_score_partial",
     "cafe_finish_partial", "cafe_family_results", "cafe_get_matrix", "cafe_get_root_likelihoods", "cafe_get_stats",
     "cafe_matrix_size", "cafe_build_matrices", "cafe_probe_fp64_mfma", "cafe_set_profiling", "cafe_debug_stamps",
+    "cafe_root_max",
 ]
 
 _lib = None
@@ -107,6 +108,8 @@ def load():
     L.cafe_get_matrix.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _f64p, C.c_size_t]
     L.cafe_get_root_likelihoods.restype = C.c_int
     L.cafe_get_root_likelihoods.argtypes = [C.c_void_p, C.c_int64, C.c_int32, _f64p, C.c_size_t]
+    L.cafe_root_max.restype = C.c_int
+    L.cafe_root_max.argtypes = [C.c_void_p, C.POINTER(CafeParams), _f64p]
     L.cafe_get_stats.restype = C.c_int
     L.cafe_get_stats.argtypes = [C.c_void_p, C.POINTER(CafeStats)]
     L.cafe_matrix_size.restype = C.c_int
@@ -225,6 +228,17 @@ class Context:
             fo.family_likelihood = _p(res["family_likelihood"], _f64p)
         self._check(self._lib.cafe_family_results(self._h, C.byref(fo)))
         return res
+
+    def root_max(self, lambdas) -> np.ndarray:
+        """max_j L_root[j] per family under the plain lambdas (p-value path, probability.cpp:313, :399)."""
+        lam = np.ascontiguousarray(lambdas, dtype=np.float64)
+        cp = CafeParams()
+        cp.model = CAFE_MODEL_BASE
+        cp.lambdas = _p(lam, _f64p)
+        cp.n_categories = 1
+        out = np.empty(self.n_families)
+        self._check(self._lib.cafe_root_max(self._h, C.byref(cp), _p(out, _f64p)))
+        return out
 
     def score_partial(self, pr: Params, device_ptr: int, stream: int = 0, alpha: float = 1.0):
         """Enqueue the shard's work; {sum lnL, rejects} lands in 2 doubles of device memory."""

@@ -95,7 +95,7 @@ struct cafe_ctx {
     // last call
     std::vector<int> slot_of;               // [node*Kmax + k]
     int K_last = 0, model_last = -1;
-    bool last_rejected = false, have_results = false;
+    bool last_rejected = false, have_results = false, rootmax_last = false;
     int n_slots_last = 0, n_kslots_last = 0;
     int64_t last_chunk_f0 = 0, last_chunk_nf = 0;
 
@@ -440,15 +440,18 @@ bool rejected(const cafe_ctx* c, const cafe_params* pr, int K) {
     return (1 - 2 * alpha) < 0;
 }
 
-int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s) {
-    if (!pr || !pr->lambdas || !pr->prior) { set_err(c, "cafe_score: lambdas and prior are required"); return CAFE_ERR_ARGUMENT; }
-    const bool gamma = pr->model == CAFE_MODEL_GAMMA;
+// rootmax: the p-value path (probability.cpp:273-317, 391-444) prunes with the plain lambda, no error model and
+// no prior, and keeps max_j L_root[j] per family instead of the scorer's reduction.
+int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bool rootmax = false) {
+    if (!pr || !pr->lambdas || (!rootmax && !pr->prior)) { set_err(c, "cafe_score: lambdas and prior are required"); return CAFE_ERR_ARGUMENT; }
+    const bool gamma = !rootmax && pr->model == CAFE_MODEL_GAMMA;
+    const bool use_err = !rootmax && c->n_dev > 0;
     const int K = gamma ? pr->n_categories : 1;
     if (gamma && (K < 1 || K > c->Kmax || !pr->multipliers || !pr->cat_probs)) {
         set_err(c, "cafe_score: gamma model needs 1..%d categories with multipliers and cat_probs", c->Kmax);
         return CAFE_ERR_ARGUMENT;
     }
-    if ((c->n_dev > 0) != (pr->error_model != nullptr)) {
+    if (!rootmax && (c->n_dev > 0) != (pr->error_model != nullptr)) {
         set_err(c, "cafe_score: error model %s but the problem was created with n_deviations=%d", pr->error_model ? "given" : "missing", c->n_dev);
         return CAFE_ERR_ARGUMENT;
     }
@@ -458,11 +461,12 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s) {
     c->have_results = false;
     c->events_valid = false;
     c->K_last = K;
-    c->model_last = pr->model;
+    c->model_last = rootmax ? CAFE_MODEL_BASE : pr->model;
+    c->rootmax_last = rootmax;
     c->stats.gemm_flops = c->stats.gemm_bytes = 0;
     c->stats.gemm_launches = 0;
 
-    c->last_rejected = rejected(c, pr, K);
+    c->last_rejected = rootmax ? !lambdas_valid(c, pr->lambdas) : rejected(c, pr, K);
     if (c->last_rejected) {
         double* hr = reinterpret_cast<double*>(c->h_stage);
         hr[0] = 0.0; hr[1] = 1.0;
@@ -517,7 +521,7 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s) {
     double* h_cat = reinterpret_cast<double*>(st + off); off += sizeof(double) * c->Kmax;
     double* h_err = reinterpret_cast<double*>(st + off);
     for (int j = 0; j < c->R; ++j) {
-        const double eq = (double)pr->prior[j];           // compute() returns float (root_equilibrium_distribution.h:15)
+        const double eq = rootmax ? 1.0 : (double)pr->prior[j];    // compute() returns float (root_equilibrium_distribution.h:15)
         h_prior[j] = eq;
         h_logprior[j] = std::log(eq);
     }
@@ -527,7 +531,7 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s) {
     HIP_TRY(c, hipMemcpyAsync(c->d_prior, h_prior, sizeof(double) * c->R, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->d_logprior, h_logprior, sizeof(double) * c->R, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->d_catprobs, h_cat, sizeof(double) * K, hipMemcpyHostToDevice, s));
-    if (c->n_dev > 0) {
+    if (use_err) {
         const size_t nb = sizeof(double) * (size_t)(c->M + 1) * c->n_dev;
         std::memcpy(h_err, pr->error_model, nb);
         HIP_TRY(c, hipMemcpyAsync(c->d_err, h_err, nb, hipMemcpyHostToDevice, s));
@@ -560,7 +564,7 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s) {
                 g.counts = c->d_counts; g.counts_ld = c->Fp; g.f0 = f0;
                 g.dst = dst; g.panel_kstride = c->panel_kstride; g.ld = (int)cols;
                 g.row_off = op.to_root ? 1 : 0; g.rows = rows; g.rows_store = rows_store; g.mode = op.mode;
-                g.err = c->n_dev > 0 ? c->d_err : nullptr; g.n_dev = c->n_dev; g.max_family_size = c->M;
+                g.err = use_err ? c->d_err : nullptr; g.n_dev = use_err ? c->n_dev : 0; g.max_family_size = c->M;
                 HIP_TRY(c, launch_leaf_gather(g, K, s));
             } else {
                 GemmArgs g{};
@@ -583,7 +587,7 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s) {
                     for (int k = 0; k < K; ++k) g.leaf_slot[l][k] = c->slot_of[(size_t)op.leaf_node[l] * c->Kmax + k];
                 }
                 g.counts = c->d_counts; g.counts_ld = c->Fp; g.f0 = f0;
-                g.err = c->n_dev > 0 ? c->d_err : nullptr; g.n_dev = c->n_dev; g.max_family_size = c->M;
+                g.err = use_err ? c->d_err : nullptr; g.n_dev = use_err ? c->n_dev : 0; g.max_family_size = c->M;
                 if (c->profile && c->gemm_ev_used + 2 <= c->gemm_ev.size()) HIP_TRY(c, hipEventRecord(c->gemm_ev[c->gemm_ev_used++], s));
                 HIP_TRY(c, launch_prune_gemm(g, K, s));
                 if (c->profile && c->gemm_ev_used + 1 <= c->gemm_ev.size()) HIP_TRY(c, hipEventRecord(c->gemm_ev[c->gemm_ev_used++], s));
@@ -595,7 +599,7 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s) {
         if (c->profile && f0 + c->chunk_cols >= c->Fp) HIP_TRY(c, hipEventRecord(c->ev[2], s));
         ReduceArgs r{};
         r.root = c->d_panels + (int64_t)c->root_panel * c->panel_stride;
-        r.panel_kstride = c->panel_kstride; r.ld = (int)cols; r.R = c->R; r.K = K; r.model = gamma ? 1 : 0;
+        r.panel_kstride = c->panel_kstride; r.ld = (int)cols; r.R = c->R; r.K = K; r.model = rootmax ? 2 : (gamma ? 1 : 0);
         r.prior = c->d_prior; r.log_prior = c->d_logprior; r.cat_probs = c->d_catprobs;
         r.f0 = f0; r.nf = std::max<int64_t>(0, std::min<int64_t>(cols, c->F_uniq - f0));
         r.fam_out = c->d_fam_out; r.fam_lik = c->d_fam_lik; r.cat_out = c->d_cat_out; r.failed = c->d_failed;
@@ -695,7 +699,7 @@ int cafe_score(cafe_ctx* ctx, const cafe_params* params, double* neg_lnl, const 
 
 int cafe_family_results(cafe_ctx* ctx, const cafe_family_out* out) {
     if (!ctx || !out) return CAFE_ERR_ARGUMENT;
-    if (ctx->last_rejected || !ctx->have_results) {
+    if (ctx->last_rejected || !ctx->have_results || ctx->rootmax_last) {
         // the reference leaves `results` empty / stale on a rejected call (gamma_core.cpp:173-179)
         set_err(ctx, "cafe_family_results: the last call was rejected (+inf) or no call was made");
         return CAFE_ERR_STATE;
@@ -725,6 +729,30 @@ int cafe_family_results(cafe_ctx* ctx, const cafe_family_out* out) {
         HIP_TRY(ctx, hipMemcpy(itmp.data(), ctx->d_failed, sizeof(int32_t) * ctx->F_uniq, hipMemcpyDeviceToHost));
         for (int64_t f = 0; f < ctx->F_all; ++f) out->failed[f] = itmp[ctx->ref_of[f]];
     }
+    return CAFE_OK;
+}
+
+int cafe_root_max(cafe_ctx* ctx, const cafe_params* params, double* out) {
+    if (!ctx) return CAFE_ERR_ARGUMENT;
+    if (!out) { set_err(ctx, "cafe_root_max: out is NULL"); return CAFE_ERR_ARGUMENT; }
+    int rc;
+    try {
+        rc = enqueue(ctx, params, ctx->d_result, ctx->stream, true);
+    } catch (const std::exception& e) {
+        set_err(ctx, "cafe_root_max: %s", e.what());
+        return CAFE_ERR_MEMORY;
+    }
+    if (rc != CAFE_OK) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->upload_pending = false;
+    collect_stats(ctx);
+    if (ctx->last_rejected) {            // an invalid lambda has no matrices: the reference would throw (matrix_cache.cpp:90)
+        set_err(ctx, "cafe_root_max: invalid lambda");
+        return CAFE_ERR_ARGUMENT;
+    }
+    std::vector<double> tmp((size_t)ctx->F_uniq);
+    HIP_TRY(ctx, hipMemcpy(tmp.data(), ctx->d_fam_out, sizeof(double) * ctx->F_uniq, hipMemcpyDeviceToHost));
+    for (int64_t f = 0; f < ctx->F_all; ++f) out[f] = tmp[ctx->ref_of[f]];
     return CAFE_OK;
 }
 

@@ -101,7 +101,7 @@ struct ReduceArgs {
     int32_t ld;
     int32_t R;
     int32_t K;
-    int32_t model;                  // 0 base, 1 gamma
+    int32_t model;                  // 0 base, 1 gamma, 2 root maximum (p-value path)
     const double* prior;            // [R]  (double)float prior
     const double* log_prior;        // [R]  log((double)float prior), host libm
     const double* cat_probs;        // [K]

@@ -126,6 +126,19 @@ __global__ __launch_bounds__(256) void root_reduce_kernel(const ReduceArgs a) {
     const int64_t fl = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (fl >= a.nf) return;
     const int64_t f = a.f0 + fl;
+    if (a.model == 2) {
+        // p-value path: the observed / simulated "max likelihood" is max_j L_root[j], no prior
+        // (probability.cpp:313, :399)
+        const double* col = a.root + fl;
+        double best = col[0];
+        for (int j = 1; j < a.R; ++j) {
+            const double L = col[(int64_t)j * a.ld];
+            if (L > best) best = L;
+        }
+        a.fam_out[f] = best;
+        a.failed[f] = 0;
+        return;
+    }
     if (a.model == 0) {
         // lnL_f = max_j( log L_j + log prior_j ), first maximum like std::max_element (base_model.cpp:94-101)
         const double* col = a.root + fl;

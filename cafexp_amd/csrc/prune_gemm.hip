@@ -40,7 +40,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-constexpr int kBStride = kBN + 16;                        // 144 doubles
+[[maybe_unused]] constexpr int kBStride = kBN + 16;                        // 144 doubles
 constexpr int a_stride(int bm) { return (bm % 32 == 16) ? bm : bm + 16; }
 
 // MI: row tile = 16*MI.  MUL: multiply into the parent panel instead of storing.  LEAF: one leaf

@@ -230,6 +230,11 @@ public:
     const clade* tree() const { return _p_tree; }
 };
 
+// Flattens (tree in `order` = children before parents, lambda structure, counts[n_families][leaves of `order`]) into a
+// cafe_problem and creates the device context; throws std::runtime_error on failure.
+cafe_ctx* create_device_context(const lambda* lam, const std::vector<const clade*>& order, const int32_t* counts, int64_t n_families,
+                                 int max_family_size, int max_root_family_size, int max_categories, int n_deviations, int device);
+
 // The two models whose infer_family_likelihoods runs on the GPU through the C ABI.
 class hip_model_base : public model {
 protected:
@@ -359,6 +364,19 @@ void read_gene_families(std::istream& in, const clade* tree, std::vector<gene_fa
 void read_error_model_file(std::istream& in, error_model* em);                                  // io.cpp:226
 void read_rootdist(std::istream& in, std::map<int, int>& out);                                  // user_data.cpp:103
 void compute_max_sizes(const std::vector<gene_family>& fams, int& max_family_size, int& max_root_family_size);   // user_data.cpp:37-46
+
+// ---------------------------------------------------------------- p-values (src/probability.cpp:255-454)
+// The Monte-Carlo part follows the reference draw for draw on the global randomizer_engine (same libstdc++
+// distributions, same traversal), so a run at the same seed sees the same simulated families; both prune batches
+// (root sizes x simulations, and the observed families) run on the GPU through cafe_root_max.
+struct pvalue_work {
+    std::vector<std::vector<double>> conditional_distribution;     // [root size][simulation], sorted
+    std::vector<double> observed_max_likelihood;                   // per family
+};
+double pvalue(double v, const std::vector<double>& conddist);                                        // probability.cpp:379
+std::vector<double> compute_pvalues(const clade* p_tree, const std::vector<gene_family>& families, const lambda* p_lambda,
+                                    int number_of_simulations, int max_family_size, int max_root_family_size, int device = 0,
+                                    pvalue_work* keep = nullptr);                                     // probability.cpp:418
 
 // ---------------------------------------------------------------- Nelder-Mead driver (src/optimizer.cpp)
 struct optimizer_result {

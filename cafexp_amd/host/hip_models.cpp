@@ -17,6 +17,35 @@ hip_model_base::~hip_model_base() {
     if (_ctx) cafe_destroy(_ctx);
 }
 
+cafe_ctx* create_device_context(const lambda* lam, const std::vector<const clade*>& order, const int32_t* counts, int64_t n_families,
+                                 int max_family_size, int max_root_family_size, int max_categories, int n_deviations, int device) {
+    const int n = (int)order.size();
+    std::map<const clade*, int> index;
+    for (int i = 0; i < n; ++i) index[order[i]] = i;
+    std::vector<int32_t> parent(n), lam_idx(n, 0), leaf_taxon(n, -1);
+    std::vector<double> blen(n, 0.0);
+    const multiple_lambda* ml = dynamic_cast<const multiple_lambda*>(lam);
+    int T = 0;
+    for (int i = 0; i < n; ++i) {
+        const clade* c = order[i];
+        parent[i] = c->is_root() ? -1 : index.at(c->get_parent());
+        blen[i] = c->get_branch_length();
+        if (ml) lam_idx[i] = ml->index_of(c);                    // by node name (lambda.cpp:34-36)
+        if (c->is_leaf()) leaf_taxon[i] = T++;
+    }
+    cafe_problem pb{};
+    pb.n_nodes = n; pb.parent = parent.data(); pb.branch_length = blen.data(); pb.lambda_index = lam_idx.data();
+    pb.leaf_taxon = leaf_taxon.data(); pb.n_taxa = T; pb.n_families = n_families; pb.counts = counts;
+    pb.max_family_size = max_family_size; pb.max_root_family_size = max_root_family_size;
+    pb.n_lambdas = lam->count(); pb.single_lambda = ml ? 0 : 1; pb.max_categories = max_categories;
+    pb.n_deviations = n_deviations;
+    pb.device = device; pb.flags = 0; pb.workspace_limit = 0;
+    char err[512];
+    cafe_ctx* ctx = cafe_create(&pb, err, sizeof err);
+    if (!ctx) throw std::runtime_error(std::string("cafe_create: ") + err);
+    return ctx;
+}
+
 void hip_model_base::ensure_context(int max_categories) {
     const int sig = _p_lambda->count() * 2 + (dynamic_cast<const multiple_lambda*>(_p_lambda) ? 1 : 0);
     if (_ctx && max_categories <= _ctx_categories && sig == _ctx_lambda_sig) return;
@@ -25,36 +54,15 @@ void hip_model_base::ensure_context(int max_categories) {
     if (!_p_tree || !_p_gene_families || _p_gene_families->empty())
         throw std::runtime_error("hip model: a tree and a non-empty family list are required");
     _order = _p_tree->post_order();
-    const int n = (int)_order.size();
-    std::map<const clade*, int> index;
-    for (int i = 0; i < n; ++i) index[_order[i]] = i;
-    std::vector<int32_t> parent(n), lam_idx(n, 0), leaf_taxon(n, -1);
-    std::vector<double> blen(n, 0.0);
     std::vector<const clade*> leaves;
-    const multiple_lambda* ml = dynamic_cast<const multiple_lambda*>(_p_lambda);
-    for (int i = 0; i < n; ++i) {
-        const clade* c = _order[i];
-        parent[i] = c->is_root() ? -1 : index.at(c->get_parent());
-        blen[i] = c->get_branch_length();
-        if (ml) lam_idx[i] = ml->index_of(c);                    // by node name (lambda.cpp:34-36)
-        if (c->is_leaf()) { leaf_taxon[i] = (int)leaves.size(); leaves.push_back(c); }
-    }
+    for (const clade* c : _order) if (c->is_leaf()) leaves.push_back(c);
     const int T = (int)leaves.size();
     const int64_t F = (int64_t)_p_gene_families->size();
     std::vector<int32_t> counts((size_t)F * T);
     for (int64_t f = 0; f < F; ++f)
         for (int t = 0; t < T; ++t) counts[(size_t)f * T + t] = (*_p_gene_families)[f].get_species_size(leaves[t]->get_taxon_name());
-
-    cafe_problem pb{};
-    pb.n_nodes = n; pb.parent = parent.data(); pb.branch_length = blen.data(); pb.lambda_index = lam_idx.data();
-    pb.leaf_taxon = leaf_taxon.data(); pb.n_taxa = T; pb.n_families = F; pb.counts = counts.data();
-    pb.max_family_size = _max_family_size; pb.max_root_family_size = _max_root_family_size;
-    pb.n_lambdas = _p_lambda->count(); pb.single_lambda = ml ? 0 : 1; pb.max_categories = max_categories;
-    pb.n_deviations = _p_error_model ? (int)_p_error_model->n_deviations() : 0;
-    pb.device = _device; pb.flags = 0; pb.workspace_limit = 0;
-    char err[512];
-    _ctx = cafe_create(&pb, err, sizeof err);
-    if (!_ctx) throw std::runtime_error(std::string("cafe_create: ") + err);
+    _ctx = create_device_context(_p_lambda, _order, counts.data(), F, _max_family_size, _max_root_family_size, max_categories,
+                                 _p_error_model ? (int)_p_error_model->n_deviations() : 0, _device);
     _ctx_categories = max_categories;
 }
 

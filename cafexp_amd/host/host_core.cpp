@@ -467,4 +467,12 @@ void compute_max_sizes(const std::vector<gene_family>& fams, int& max_family_siz
     max_family_size = mx + std::max(50, mx / 5);                                       // user_data.cpp:46
 }
 
+// ---------------------------------------------------------------- p-values
+double pvalue(double v, const std::vector<double>& conddist) {                  // probability.cpp:379-389
+    int idx = (int)conddist.size() - 1;
+    auto bound = std::upper_bound(conddist.begin(), conddist.end(), v);
+    if (bound != conddist.end()) idx = (int)(bound - conddist.begin());
+    return idx / (double)conddist.size();
+}
+
 }  // namespace cafe

@@ -169,7 +169,18 @@ static void test_optimizer() {
     CHECK(threw);
 }
 
+static void test_pvalue() {                                   // test.cpp:1175-1183
+    std::vector<double> cd(10);
+    double n = 0;
+    for (auto& x : cd) x = (n += 0.01);
+    CLOSE(pvalue(0.05, cd), 0.5, 0.001);
+    CLOSE(pvalue(0.0001, cd), 0.0, 0.001);
+    CLOSE(pvalue(0.099, cd), 0.9, 0.001);
+    CHECK(pvalue(1.0, cd) == 0.9);                            // beyond the last entry: index size-1, not size
+}
+
 int main() {
+    test_pvalue();
     test_newick();
     test_families_and_sizes();
     test_error_model();

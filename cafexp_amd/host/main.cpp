@@ -17,7 +17,8 @@ using namespace cafe;
 static void usage() {
     std::fprintf(stderr,
         "usage: cafexp_hip -t TREE -i FAMILIES [-l LAMBDA | -m L1,L2,.. -y LAMBDA_TREE | -y LAMBDA_TREE] [-k K] [-a ALPHA]\n"
-        "                  [-e [ERRMODEL]] [-p [POISSON_LAMBDA]] [-f ROOTDIST] [-z] [-s SEED] [-I MAXITER] [-d DEVICE] [--reps N] [--family-out FILE] [-o OUTDIR] [--limit N]\n");
+        "                  [-e [ERRMODEL]] [-p [POISSON_LAMBDA]] [-f ROOTDIST] [-z] [-s SEED] [-I MAXITER] [-d DEVICE] [--reps N] [--family-out FILE] [-o OUTDIR] [--limit N]\n"
+        "                  [--pvalues NSIM [--pvalues-out FILE] [--pvalues-cond FILE:K]] [--sizes M,R]\n");
 }
 
 static std::string slurp_first_line(const std::string& path) {
@@ -36,6 +37,8 @@ static void print_num(const char* key, double v, bool comma = true) {
 
 int main(int argc, char** argv) {
     std::string tree_path, fam_path, lambda_tree_path, multi, err_path, rootdist_path, family_out, out_dir;
+    std::string pvalues_out, pvalues_cond;
+    int pvalue_sims = 0, force_m = -1, force_r = -1;
     long limit = -1;
     double fixed_lambda = 0, fixed_alpha = -1, poisson = 0;
     int k = 1, device = 0, max_iter = 300, reps = 1;
@@ -64,6 +67,14 @@ int main(int argc, char** argv) {
         else if (a == "--family-out") family_out = next();
         else if (a == "-o") out_dir = next();
         else if (a == "--limit") limit = std::stol(next());
+        else if (a == "--sizes") {                               // M,R instead of the data-derived maxima (tests)
+            std::string v = next();
+            const size_t comma = v.find(',');
+            force_m = std::stoi(v.substr(0, comma)); force_r = std::stoi(v.substr(comma + 1));
+        }
+        else if (a == "--pvalues") pvalue_sims = std::stoi(next());
+        else if (a == "--pvalues-out") pvalues_out = next();
+        else if (a == "--pvalues-cond") pvalues_cond = next();
         else { usage(); return 2; }
     }
     if (tree_path.empty() || fam_path.empty()) { usage(); return 2; }
@@ -77,6 +88,7 @@ int main(int argc, char** argv) {
             read_gene_families(f, d.p_tree.get(), d.gene_families);
         }
         compute_max_sizes(d.gene_families, d.max_family_size, d.max_root_family_size);
+        if (force_m > 0) { d.max_family_size = force_m; d.max_root_family_size = force_r; }
         if (!err_path.empty()) {
             std::ifstream f(err_path);
             if (!f.is_open()) throw std::runtime_error("Failed to open " + err_path + ". Exiting...");
@@ -158,6 +170,33 @@ int main(int argc, char** argv) {
             std::ofstream lf(out_dir + "/" + mdl->name() + "_family_likelihoods.txt");
             mdl->write_family_likelihoods(lf);
         }
+        // compute_pvalues with the model's plain lambda (execute.cpp:153-161); 1000 simulations in the reference
+        std::vector<double> pvalues;
+        double pvalue_s = 0;
+        if (pvalue_sims > 0) {
+            pvalue_work work;
+            auto t0 = std::chrono::steady_clock::now();
+            pvalues = compute_pvalues(d.p_tree.get(), d.gene_families, mdl->get_lambda(), pvalue_sims, d.max_family_size, d.max_root_family_size,
+                                      device, &work);
+            pvalue_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (!pvalues_out.empty()) {
+                std::ofstream f(pvalues_out);
+                f.precision(17);
+                f << "#FamilyID\tpvalue\tobserved max likelihood\n";
+                for (size_t i = 0; i < pvalues.size(); ++i)
+                    f << d.gene_families[i].id() << '\t' << pvalues[i] << '\t' << work.observed_max_likelihood[i] << '\n';
+            }
+            if (!pvalues_cond.empty()) {                         // FILE:K -> the first K sorted conditional distributions, one per line
+                const size_t colon = pvalues_cond.rfind(':');
+                const size_t kdump = std::min<size_t>(work.conditional_distribution.size(), std::stoul(pvalues_cond.substr(colon + 1)));
+                std::ofstream f(pvalues_cond.substr(0, colon));
+                f.precision(17);
+                for (size_t i = 0; i < kdump; ++i) {
+                    for (size_t j = 0; j < work.conditional_distribution[i].size(); ++j) f << (j ? "\t" : "") << work.conditional_distribution[i][j];
+                    f << '\n';
+                }
+            }
+        }
         std::printf("{\"model\": \"%s\", ", mdl->name().c_str());
         print_num("neg_lnl", score);
         std::printf("\"n_families\": %zu, \"max_family_size\": %d, \"max_root_family_size\": %d, \"seconds_per_call\": %.6f, ",
@@ -178,6 +217,11 @@ int main(int argc, char** argv) {
             std::printf(", \"search\": {\"iterations\": %d, \"scorer_calls\": %d, \"seconds\": %.3f, ", opt.num_iterations, opt.num_scorer_calls, search_s);
             print_num("score", opt.score, false);
             std::printf("}");
+        }
+        if (pvalue_sims > 0) {
+            size_t sig = 0;
+            for (double p : pvalues) if (p < 0.05) ++sig;
+            std::printf(", \"pvalues\": {\"simulations\": %d, \"seconds\": %.3f, \"significant_at_0.05\": %zu}", pvalue_sims, pvalue_s, sig);
         }
         std::printf("}\n");
     } catch (const std::exception& e) {

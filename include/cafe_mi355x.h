@@ -141,6 +141,13 @@ double cafe_finish_partial(const double host_partial[2]);
 /* Per-family results of the last call (valid after the stream was synchronised). */
 int cafe_family_results(cafe_ctx* ctx, const cafe_family_out* out);
 
+/* P-value path.  For every family of the context: max_j L_root[j], the "observed max likelihood"
+ * of compute_tree_pvalue (probability.cpp:391-399) and, on a context holding simulated families, the entries of
+ * get_random_probabilities (probability.cpp:273-317, before its sort).  As in the reference the prune uses the
+ * plain lambdas (one category, no multiplier), no error model and no prior: params->lambdas is the only field
+ * read.  out[n_families].  cafe_family_results is not meaningful after this call. */
+int cafe_root_max(cafe_ctx* ctx, const cafe_params* params, double* out);
+
 /* Introspection for parity tests: the transition matrix the last call built for the branch above
  * `node` in category k (N x N row-major, N = max(M,R)+1: matrix_cache::get_matrix; for an interior
  * branch the columns c > M, which the prune never reads, are not materialised and come back 0), and the root

@@ -538,6 +538,66 @@ double orc_score_base(const orc_problem* pb, const orc_params* pr, double* famil
     return -total;
 }
 
+/* The p-value path's likelihood of a family: max_j L_root[j] with the plain lambda, no error model, no prior
+ * (get_random_probabilities probability.cpp:309-313; compute_tree_pvalue probability.cpp:397-399). */
+int orc_root_max(const orc_problem* pb, const orc_params* pr, double* out) {
+    if (!lambdas_valid(pb, pr)) return 1;
+    orc_params q = *pr;
+    q.error_model = NULL;                               /* both call sites pass a NULL error model */
+    q.n_categories = 1;
+    mat_cache cache;
+    double one = 1.0;
+    if (build_all(pb, &q, &one, 1, &cache)) return 2;
+    int M = pb->max_family_size, R = pb->max_root_family_size;
+    int stride = (M + 1 > R ? M + 1 : R);
+    int64_t F = pb->n_families;
+    int failed = 0;
+#pragma omp parallel
+    {
+        double* L = (double*)malloc(sizeof(double) * (size_t)stride * (pb->tree.n_nodes + 2));
+        double* factor = L + (size_t)stride * pb->tree.n_nodes;
+        double* rootv = factor + stride;
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t f = 0; f < F; ++f) {
+            if (prune_with_cache(pb, &q, &cache, pb->counts + f * pb->n_taxa, 1.0, L, stride, factor, rootv)) {
+#pragma omp atomic write
+                failed = 1;
+                continue;
+            }
+            double best = rootv[0];                     /* std::max_element */
+            for (int j = 1; j < R; ++j) if (rootv[j] > best) best = rootv[j];
+            out[f] = best;
+        }
+        free(L);
+    }
+    cache_free(&cache);
+    return failed ? 3 : 0;
+}
+
+/* probability.cpp:379-389: position of v in the sorted conditional distribution (std::upper_bound), as a fraction */
+double orc_pvalue(double v, const double* conddist, int n) {
+    int lo = 0, hi = n;                                 /* first element > v */
+    while (lo < hi) {
+        int mid = lo + (hi - lo) / 2;
+        if (!(v < conddist[mid])) lo = mid + 1; else hi = mid;
+    }
+    int idx = (lo != n) ? lo : n - 1;
+    return idx / (double)n;
+}
+
+/* probability.cpp:401-407 for every family: the maximum over root sizes s of pvalue(observed, cond[s]);
+ * cond is [R][nsim], every row sorted ascending */
+void orc_tree_pvalues(const double* observed, int64_t F, const double* cond, int R, int nsim, double* out) {
+    for (int64_t f = 0; f < F; ++f) {
+        double best = 0.0;
+        for (int s = 0; s < R; ++s) {
+            double p = orc_pvalue(observed[f], cond + (size_t)s * nsim, nsim);
+            if (s == 0 || p > best) best = p;
+        }
+        out[f] = best;
+    }
+}
+
 /* gamma_core.cpp:123-246 */
 double orc_score_gamma(const orc_problem* pb, const orc_params* pr, double* cat_lik, double* fam_lik) {
     double t_start = now_s();

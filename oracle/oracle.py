@@ -84,6 +84,12 @@ def lib():
         L.orc_num_threads.restype = C.c_int
         L.orc_last_timings.argtypes = [_f64p, _f64p]
         L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_root_max.restype = C.c_int
+        L.orc_root_max.argtypes = [C.POINTER(_Problem), C.POINTER(_Params), _f64p]
+        L.orc_pvalue.restype = C.c_double
+        L.orc_pvalue.argtypes = [C.c_double, _f64p, C.c_int]
+        L.orc_tree_pvalues.restype = None
+        L.orc_tree_pvalues.argtypes = [_f64p, C.c_int64, _f64p, C.c_int, C.c_int, _f64p]
         _lib = L
     return _lib
 
@@ -207,6 +213,32 @@ def score_gamma(pb, pr, fast: bool = False, per_family: bool = False):
     fam = np.zeros(pb.n_families, dtype=np.float64) if per_family else None
     v = lib().orc_score_gamma(C.byref(b.pb), C.byref(b.pr), _p(cat, _f64p), _p(fam, _f64p))
     return (v, cat, fam) if per_family else v
+
+
+def root_max(pb, lambdas, fast: bool = False) -> np.ndarray:
+    """max_j L_root[j] per family: plain lambda, no error model, no prior (probability.cpp:313, :399)."""
+    from cafexp_amd.problem import Params
+    pr = Params(lambdas=np.asarray(lambdas, dtype=np.float64), prior=np.ones(pb.max_root_family_size, dtype=np.float32))
+    b = _Bound(pb, pr, fast)
+    out = np.empty(pb.n_families, dtype=np.float64)
+    rc = lib().orc_root_max(C.byref(b.pb), C.byref(b.pr), _p(out, _f64p))
+    if rc:
+        raise RuntimeError("oracle: root_max failed (%d)" % rc)
+    return out
+
+
+def pvalue(v: float, conddist) -> float:
+    c = np.ascontiguousarray(conddist, dtype=np.float64)
+    return lib().orc_pvalue(float(v), _p(c, _f64p), len(c))
+
+
+def tree_pvalues(observed, cond) -> np.ndarray:
+    """cond: [R][nsim], rows sorted ascending -> per-family max over root sizes (probability.cpp:401-407)."""
+    obs = np.ascontiguousarray(observed, dtype=np.float64)
+    c = np.ascontiguousarray(cond, dtype=np.float64)
+    out = np.empty(len(obs), dtype=np.float64)
+    lib().orc_tree_pvalues(_p(obs, _f64p), len(obs), _p(c, _f64p), c.shape[0], c.shape[1], _p(out, _f64p))
+    return out
 
 
 def score(pb, pr, fast: bool = False):

@@ -19,6 +19,9 @@
 //             [errfile=] [prior=uniform|poisson:X] [rootdist=file] [rootfilter=1] [limit=N]
 //             [m= r=]  -> -lnL, per-family table, wall seconds
 //   time_matrices n= lambda= count= t0=          wall seconds of precalculate_matrices for `count` branch lengths
+//   pvalues   tree= families= lambda=|lambdas= lambda_tree= [nsim=1000] [seed=10] [ncond=0] [limit=] [m= r=]
+//             compute_pvalues at a fixed seed of the global engine; ncond > 0 also prints the sorted conditional
+//             distributions get_random_probabilities returns for root sizes 0..ncond-1 (same seed, same order)
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -232,6 +235,50 @@ static int job_score(const kv_t& kv) {
     return 0;
 }
 
+static int job_pvalues(const kv_t& kv) {
+    input_parameters p;
+    p.tree_file_path = gets(kv, "tree");
+    p.input_file_path = gets(kv, "families");
+    if (has(kv, "lambda")) p.fixed_lambda = getd(kv, "lambda");
+    if (has(kv, "lambdas")) { p.fixed_multiple_lambdas = gets(kv, "lambdas"); p.lambda_tree_file_path = gets(kv, "lambda_tree"); }
+    user_data d;
+    d.read_datafiles(p);
+    if (geti(kv, "rootfilter", 1)) {
+        auto rem = std::remove_if(d.gene_families.begin(), d.gene_families.end(), [&](const gene_family& fam) {
+            return !fam.exists_at_root(d.p_tree); });
+        d.gene_families.erase(rem, d.gene_families.end());
+    }
+    if (has(kv, "limit")) {
+        size_t lim = (size_t)geti(kv, "limit");
+        if (d.gene_families.size() > lim) d.gene_families.resize(lim);
+    }
+    if (has(kv, "m")) d.max_family_size = geti(kv, "m");
+    if (has(kv, "r")) d.max_root_family_size = geti(kv, "r");
+    const int nsim = geti(kv, "nsim", 1000), seed = geti(kv, "seed", 10), ncond = geti(kv, "ncond", 0);
+    // execute.cpp:158-161
+    matrix_cache cache(std::max(d.max_family_size, d.max_root_family_size) + 1);
+    cache.precalculate_matrices(get_lambda_values(d.p_lambda), d.p_tree->get_branch_lengths());
+    randomizer_engine.seed(seed);
+    double t0 = now();
+    auto pv = compute_pvalues(d.p_tree, d.gene_families, d.p_lambda, cache, nsim, d.max_family_size, d.max_root_family_size);
+    double dt = now() - t0;
+    printf("{\"n_families\": %zu, \"max_family_size\": %d, \"max_root_family_size\": %d, \"nsim\": %d, \"seed\": %d, \"seconds\": %.6f, \"threads\": %d, ",
+        d.gene_families.size(), d.max_family_size, d.max_root_family_size, nsim, seed, dt, omp_get_max_threads());
+    parr("pvalues", pv);
+    if (ncond > 0) {
+        randomizer_engine.seed(seed);
+        std::vector<double> flat;
+        for (int i = 0; i < ncond; ++i) {
+            auto c = get_random_probabilities(d.p_tree, nsim, i, d.max_family_size, d.max_root_family_size, d.p_lambda, cache, NULL);
+            flat.insert(flat.end(), c.begin(), c.end());
+        }
+        printf(", \"ncond\": %d, ", ncond);
+        parr("cond", flat);
+    }
+    printf("}\n");
+    return 0;
+}
+
 static int job_time_matrices(const kv_t& kv) {
     int n = geti(kv, "n"), count = geti(kv, "count", 1);
     double lambda = getd(kv, "lambda"), t0v = getd(kv, "t0", 1.0);
@@ -260,6 +307,7 @@ int main(int argc, char** argv) {
         if (job == "prune") return job_prune(kv);
         if (job == "score") return job_score(kv);
         if (job == "time_matrices") return job_time_matrices(kv);
+        if (job == "pvalues") return job_pvalues(kv);
     } catch (std::exception& e) {
         fprintf(stderr, "ref_harness: %s\n", e.what());
         return 1;

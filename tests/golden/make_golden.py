@@ -48,7 +48,37 @@ def write_synth(name, n_taxa, n_families, seed, max_count, lam_sim, root_cap, la
             f.write(rec(tree) + ";\n")
 
 
+def make_pvalues():
+    """tests/golden/ref_pvalues.json: compute_pvalues / get_random_probabilities of the real reference at a fixed
+    seed of its global engine.  `cond` = sorted conditional distributions of root sizes 0..ncond-1."""
+    data = lambda n: os.path.join(D, n)
+    jobs = {
+        # the reference's own known-answer case test.cpp:2229 (expects 0.666667)
+        "test2229": dict(tree=data("ab_tree.txt"), families=data("ab_families.txt"), m=10, r=8, nsim=3, seed=10, ncond=8, rootfilter=0, **{"lambda": 0.05}),
+        "mammals": dict(tree=data("mammals_tree.txt"), families=data("mammal_gene_families.txt"), nsim=1000, seed=10, ncond=4, limit=600,
+                        **{"lambda": 0.0018174300635539}),
+        "mammals_lambda_tree": dict(tree=data("mammals_tree.txt"), families=data("mammal_gene_families.txt"), nsim=100, seed=7, ncond=3, limit=300,
+                                    lambdas="0.01,0.05", lambda_tree=data("chimphuman_separate_lambda.txt")),
+        "synth20": dict(tree=data("synth20_tree.txt"), families=data("synth20_families.txt"), nsim=50, seed=3, ncond=3, **{"lambda": 0.004}),
+    }
+    out = {"generator": "tests/golden/make_golden.py pvalues", "source": "oracle/_ref/ref_harness pvalues (real reference, std::mt19937 seeded as given)", "cases": {}}
+    for name, kv in jobs.items():
+        print("ref pvalues:", name, flush=True)
+        r = O.ref("pvalues", **kv)
+        e = {"args": {k: (os.path.basename(v) if isinstance(v, str) and os.sep in v else v) for k, v in kv.items()}}
+        e.update(r)
+        out["cases"][name] = e
+    path = os.path.join(HERE, "ref_pvalues.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0, separators=(",", ":"))
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 def main():
+    if sys.argv[1:] == ["pvalues"]:
+        if not O.have_ref():
+            raise SystemExit("oracle/_ref/ref_harness missing: run `make -C oracle ref` in the build container")
+        return make_pvalues()
     if not O.have_ref():
         raise SystemExit("oracle/_ref/ref_harness missing: run `make -C oracle ref` in the build container")
     g = {"generator": "tests/golden/make_golden.py", "source": "oracle/_ref/ref_harness (real reference, g++ -O3 -fopenmp, no BLAS)"}
