@@ -63,7 +63,7 @@ EXPORTS = [
     "cafe_abi_version", "cafe_create", "cafe_destroy", "cafe_last_error", "cafe_score", "cafe_score_partial",
     "cafe_finish_partial", "cafe_family_results", "cafe_get_matrix", "cafe_get_root_likelihoods", "cafe_get_stats",
     "cafe_matrix_size", "cafe_build_matrices", "cafe_probe_fp64_mfma", "cafe_set_profiling", "cafe_debug_stamps",
-    "cafe_root_max",
+    "cafe_root_max", "cafe_reconstruct", "cafe_branch_probabilities",
 ]
 
 _lib = None
@@ -110,6 +110,10 @@ def load():
     L.cafe_get_root_likelihoods.argtypes = [C.c_void_p, C.c_int64, C.c_int32, _f64p, C.c_size_t]
     L.cafe_root_max.restype = C.c_int
     L.cafe_root_max.argtypes = [C.c_void_p, C.POINTER(CafeParams), _f64p]
+    L.cafe_reconstruct.restype = C.c_int
+    L.cafe_reconstruct.argtypes = [C.c_void_p, C.POINTER(CafeParams), _f32p, _i32p]
+    L.cafe_branch_probabilities.restype = C.c_int
+    L.cafe_branch_probabilities.argtypes = [C.c_void_p, C.POINTER(CafeParams), _i32p, _f64p]
     L.cafe_get_stats.restype = C.c_int
     L.cafe_get_stats.argtypes = [C.c_void_p, C.POINTER(CafeStats)]
     L.cafe_matrix_size.restype = C.c_int
@@ -162,6 +166,8 @@ class Context:
             raise CafeError(err.value.decode() or "cafe_create failed")
         self.problem = pb
         self.R = pb.max_root_family_size
+        self.M = pb.max_family_size
+        self.n_nodes = pb.n_nodes
         self.n_families = pb.n_families
         self._keep = []          # cafe_create copied everything
 
@@ -238,6 +244,42 @@ class Context:
         cp.n_categories = 1
         out = np.empty(self.n_families)
         self._check(self._lib.cafe_root_max(self._h, C.byref(cp), _p(out, _f64p)))
+        return out
+
+    def reconstruct(self, lambdas, root_prior, multipliers=None) -> np.ndarray:
+        """Pupko joint reconstruction -> int32 [K][n_families][n_nodes] (gene_family_reconstructor.cpp:13-165).
+        root_prior[j] = compute(j), j = 0..min(M, R)."""
+        lam = np.ascontiguousarray(lambdas, dtype=np.float64)
+        rp = np.ascontiguousarray(root_prior, dtype=np.float32)
+        if len(rp) < min(self.M, self.R) + 1:
+            raise CafeError("root_prior needs min(M, R) + 1 entries")
+        cp = CafeParams()
+        cp.lambdas = _p(lam, _f64p)
+        K = 1
+        mult = None
+        if multipliers is not None:
+            mult = np.ascontiguousarray(multipliers, dtype=np.float64)
+            K = len(mult)
+            cp.model = CAFE_MODEL_GAMMA
+            cp.multipliers = _p(mult, _f64p)
+        else:
+            cp.model = CAFE_MODEL_BASE
+        cp.n_categories = K
+        out = np.empty((K, self.n_families, self.n_nodes), dtype=np.int32)
+        self._check(self._lib.cafe_reconstruct(self._h, C.byref(cp), _p(rp, _f32p), _p(out, _i32p)))
+        return out
+
+    def branch_probabilities(self, lambdas, sizes) -> np.ndarray:
+        """compute_viterbi_sum for every (family, node); NaN = invalid (gene_family_reconstructor.cpp:361-400)."""
+        lam = np.ascontiguousarray(lambdas, dtype=np.float64)
+        sz = np.ascontiguousarray(sizes, dtype=np.int32)
+        assert sz.shape == (self.n_families, self.n_nodes)
+        cp = CafeParams()
+        cp.model = CAFE_MODEL_BASE
+        cp.lambdas = _p(lam, _f64p)
+        cp.n_categories = 1
+        out = np.empty((self.n_families, self.n_nodes))
+        self._check(self._lib.cafe_branch_probabilities(self._h, C.byref(cp), _p(sz, _i32p), _p(out, _f64p)))
         return out
 
     def score_partial(self, pr: Params, device_ptr: int, stream: int = 0, alpha: float = 1.0):

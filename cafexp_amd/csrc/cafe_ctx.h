@@ -1,0 +1,116 @@
+// Internal: the context behind the C ABI handle, shared by cafe_ctx.hip (scorer path) and reconstruct.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/cafe_mi355x.h"
+#include "cafe_kernels.h"
+
+namespace cafe {
+
+struct Op {
+    int type;                   // 0 gather, 1 gemm
+    int dst_panel;
+    int src_panel;              // gemm
+    int child;                  // gemm: child node (its branch's matrix)
+    int n_leaf;                 // gather
+    int leaf_node[kMaxLeafPerOp];
+    int mode;                   // 0 store, 1 multiply
+    bool to_root;
+};
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline int64_t round_up64(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+}  // namespace cafe
+
+struct cafe_ctx {
+    // problem
+    int n_nodes = 0, n_taxa = 0, M = 0, R = 0, N = 0, n_lambdas = 1, single_lambda = 1, Kmax = 1, n_dev = 0, device = 0;
+    int root = -1;
+    std::vector<int> parent, lam_idx, leaf_taxon;
+    std::vector<double> blen;
+    std::vector<std::vector<int>> children;
+    int64_t F_all = 0, F_uniq = 0, Fp = 0;
+    std::vector<int64_t> ref_of;            // family -> unique column
+    std::vector<double> weights;
+
+    // schedule
+    std::vector<cafe::Op> ops;
+    int n_panels = 0, root_panel = -1;
+
+    // device state
+    bool device_ready = false;
+    hipStream_t stream = nullptr;
+    hipStream_t last_stream = nullptr;       // stream the last call was enqueued on
+    int32_t* d_counts = nullptr;
+    double* d_weights = nullptr;
+    cafe::MatrixPool pool{nullptr, 0, 0, 0, 0, 0, 0};     // row-major matrices of leaf branches (K3)
+    cafe::MatrixPool kpool{nullptr, 0, 0, 0, 0, 0, 1};    // k-major matrices of interior branches (K2)
+    int max_slots = 0, max_kslots = 0;
+    cafe::SlotParam* d_slots = nullptr;                   // [max_slots] row-major, then [max_kslots] k-major
+    double* d_panels = nullptr;
+    int64_t panel_stride = 0;               // doubles per panel
+    int64_t panel_kstride = 0;              // doubles per category inside a panel
+    int rows_pad = 0, kc = 0;
+    int64_t chunk_cols = 0;
+    double *d_prior = nullptr, *d_logprior = nullptr, *d_catprobs = nullptr, *d_err = nullptr;
+    double *d_fam_out = nullptr, *d_fam_lik = nullptr, *d_cat_out = nullptr;
+    int32_t* d_failed = nullptr;
+    double* d_scratch = nullptr;
+    int n_scratch = 1024;
+    double* d_result = nullptr;
+    unsigned long long* d_stamps = nullptr;     // diagnostic block timeline of the LAST K2 launch (CAFE_GEMM_STAMPS=1)
+    size_t stamps_words = 0;
+    // pinned staging
+    char* h_stage = nullptr;
+    size_t stage_bytes = 0;
+    double* h_result = nullptr;
+    hipEvent_t ev_upload = nullptr;
+    bool upload_pending = false;
+
+    // last call
+    std::vector<int> slot_of;               // [node*Kmax + k]
+    int K_last = 0, model_last = -1;
+    bool last_rejected = false, have_results = false, rootmax_last = false;
+    int n_slots_last = 0, n_kslots_last = 0;
+    int64_t last_chunk_f0 = 0, last_chunk_nf = 0;
+
+    // measurement
+    int profile = 1;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> gemm_ev;
+    size_t gemm_ev_used = 0;
+    bool events_valid = false;
+    cafe_stats stats{};
+
+    std::string err;
+};
+
+namespace cafe {
+
+void set_err(cafe_ctx* c, const char* fmt, ...);
+
+#define HIP_TRY(c, expr)                                                                    \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            cafe::set_err(c, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return CAFE_ERR_DEVICE;                                                         \
+        }                                                                                   \
+    } while (0)
+
+bool lambdas_valid(const cafe_ctx* c, const double* lam);
+// One slot per distinct quantized (lambda * multiplier, t) and layout (matrix_cache.h:42-61), parameters uploaded on
+// `s`, K1 launched: afterwards slot_of[node * Kmax + k] names the matrix of every branch and category.
+int prepare_matrices(cafe_ctx* c, const double* lambdas, const double* multipliers, int K, hipStream_t s);
+// Pupko reconstruction and Viterbi branch probabilities (reconstruct.hip)
+int reconstruct_impl(cafe_ctx* c, const cafe_params* pr, const float* root_prior, int32_t* states);
+int branch_probabilities_impl(cafe_ctx* c, const cafe_params* pr, const int32_t* sizes, double* out);
+
+}  // namespace cafe

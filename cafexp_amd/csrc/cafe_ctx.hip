@@ -24,93 +24,11 @@
 #include <unordered_map>
 #include <vector>
 
-#include "../../include/cafe_mi355x.h"
-#include "cafe_kernels.h"
+#include "cafe_ctx.h"
 
 using namespace cafe;
 
-namespace {
-
-struct Op {
-    int type;                   // 0 gather, 1 gemm
-    int dst_panel;
-    int src_panel;              // gemm
-    int child;                  // gemm: child node (its branch's matrix)
-    int n_leaf;                 // gather
-    int leaf_node[kMaxLeafPerOp];
-    int mode;                   // 0 store, 1 multiply
-    bool to_root;
-};
-
-inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
-inline int64_t round_up64(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
-
-}  // namespace
-
-struct cafe_ctx {
-    // problem
-    int n_nodes = 0, n_taxa = 0, M = 0, R = 0, N = 0, n_lambdas = 1, single_lambda = 1, Kmax = 1, n_dev = 0, device = 0;
-    int root = -1;
-    std::vector<int> parent, lam_idx, leaf_taxon;
-    std::vector<double> blen;
-    std::vector<std::vector<int>> children;
-    int64_t F_all = 0, F_uniq = 0, Fp = 0;
-    std::vector<int64_t> ref_of;            // family -> unique column
-    std::vector<double> weights;
-
-    // schedule
-    std::vector<Op> ops;
-    int n_panels = 0, root_panel = -1;
-
-    // device state
-    bool device_ready = false;
-    hipStream_t stream = nullptr;
-    hipStream_t last_stream = nullptr;       // stream the last call was enqueued on
-    int32_t* d_counts = nullptr;
-    double* d_weights = nullptr;
-    MatrixPool pool{nullptr, 0, 0, 0, 0, 0, 0};     // row-major matrices of leaf branches (K3)
-    MatrixPool kpool{nullptr, 0, 0, 0, 0, 0, 1};    // k-major matrices of interior branches (K2)
-    int max_slots = 0, max_kslots = 0;
-    SlotParam* d_slots = nullptr;                   // [max_slots] row-major, then [max_kslots] k-major
-    double* d_panels = nullptr;
-    int64_t panel_stride = 0;               // doubles per panel
-    int64_t panel_kstride = 0;              // doubles per category inside a panel
-    int rows_pad = 0, kc = 0;
-    int64_t chunk_cols = 0;
-    double *d_prior = nullptr, *d_logprior = nullptr, *d_catprobs = nullptr, *d_err = nullptr;
-    double *d_fam_out = nullptr, *d_fam_lik = nullptr, *d_cat_out = nullptr;
-    int32_t* d_failed = nullptr;
-    double* d_scratch = nullptr;
-    int n_scratch = 1024;
-    double* d_result = nullptr;
-    unsigned long long* d_stamps = nullptr;     // diagnostic block timeline of the LAST K2 launch (CAFE_GEMM_STAMPS=1)
-    size_t stamps_words = 0;
-    // pinned staging
-    char* h_stage = nullptr;
-    size_t stage_bytes = 0;
-    double* h_result = nullptr;
-    hipEvent_t ev_upload = nullptr;
-    bool upload_pending = false;
-
-    // last call
-    std::vector<int> slot_of;               // [node*Kmax + k]
-    int K_last = 0, model_last = -1;
-    bool last_rejected = false, have_results = false, rootmax_last = false;
-    int n_slots_last = 0, n_kslots_last = 0;
-    int64_t last_chunk_f0 = 0, last_chunk_nf = 0;
-
-    // measurement
-    int profile = 1;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    std::vector<hipEvent_t> gemm_ev;
-    size_t gemm_ev_used = 0;
-    bool events_valid = false;
-    cafe_stats stats{};
-
-    std::string err;
-};
-
-namespace {
+namespace cafe {
 
 void set_err(cafe_ctx* c, const char* fmt, ...) {
     char buf[512];
@@ -121,14 +39,9 @@ void set_err(cafe_ctx* c, const char* fmt, ...) {
     c->err = buf;
 }
 
-#define HIP_TRY(c, expr)                                                                    \
-    do {                                                                                    \
-        hipError_t e_ = (expr);                                                             \
-        if (e_ != hipSuccess) {                                                             \
-            set_err(c, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-            return CAFE_ERR_DEVICE;                                                         \
-        }                                                                                   \
-    } while (0)
+}  // namespace cafe
+
+namespace {
 
 // Sethi-Ullman style need: panels live while evaluating node v (leaves need none).
 int panel_need(const cafe_ctx* c, int v, std::vector<int>& need) {
@@ -414,11 +327,66 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     return CAFE_OK;
 }
 
+}  // namespace
+
+namespace cafe {
+
 bool lambdas_valid(const cafe_ctx* c, const double* lam) {
     if (c->single_lambda) return lam[0] > 0;                                   // lambda.h:58
     for (int i = 0; i < c->n_lambdas; ++i) if (lam[i] < 0) return false;       // lambda.cpp:59
     return true;
 }
+
+// matrix keys: one slot per distinct (lambda_q, t_q) and layout; de-quantized like matrix_cache.cpp:148-149
+int prepare_matrices(cafe_ctx* c, const double* lambdas, const double* multipliers, int K, hipStream_t s) {
+    SlotParam* h_slots = reinterpret_cast<SlotParam*>(c->h_stage);
+    SlotParam* h_kslots = h_slots + c->max_slots;
+    std::map<std::pair<long, long>, int> key_slot[2];
+    int n_slots = 0, n_kslots = 0;
+    for (int v = 0; v < c->n_nodes; ++v) {
+        if (v == c->root) continue;
+        const int layout = c->leaf_taxon[v] >= 0 ? 0 : 1;
+        for (int k = 0; k < K; ++k) {
+            const double mult = multipliers ? multipliers[k] : 1.0;
+            const double lam = lambdas[c->lam_idx[v]] * mult;                   // lambda.h:39, :82-88
+            long lq, tq;
+            quantize(lam, c->blen[v], &lq, &tq);
+            auto key = std::make_pair(tq, lq);
+            auto it = key_slot[layout].find(key);
+            int slot;
+            if (it == key_slot[layout].end()) {
+                slot = layout ? n_kslots++ : n_slots++;
+                key_slot[layout].emplace(key, slot);
+                const double lambda_q = double(lq) / 1000000000.0, t_q = double(tq) / 1000.0;
+                const double alpha = lambda_q * t_q / (1 + lambda_q * t_q);
+                const double coeff = 1 - 2 * alpha;
+                SlotParam sp;
+                sp.alpha = alpha;
+                sp.oma2 = (1 - alpha) * (1 - alpha);
+                sp.zero = !(coeff > 0 && coeff != 1);       // saturated (coeff < 0) or degenerate: rows s>=1 are 0
+                sp.pad = 0;
+                (layout ? h_kslots : h_slots)[slot] = sp;
+            } else {
+                slot = it->second;
+            }
+            c->slot_of[(size_t)v * c->Kmax + k] = slot;
+        }
+    }
+    c->n_slots_last = n_slots;
+    c->n_kslots_last = n_kslots;
+    c->stats.n_matrices = n_slots + n_kslots;
+    if (n_slots) HIP_TRY(c, hipMemcpyAsync(c->d_slots, h_slots, sizeof(SlotParam) * n_slots, hipMemcpyHostToDevice, s));
+    if (n_kslots) HIP_TRY(c, hipMemcpyAsync(c->d_slots + c->max_slots, h_kslots, sizeof(SlotParam) * n_kslots, hipMemcpyHostToDevice, s));
+    if (c->profile) HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    HIP_TRY(c, launch_bd_matrix_build(c->pool, c->d_slots, n_slots, s));
+    HIP_TRY(c, launch_bd_matrix_build(c->kpool, c->d_slots + c->max_slots, n_kslots, s));
+    if (c->profile) HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    return CAFE_OK;
+}
+
+}  // namespace cafe
+
+namespace {
 
 // Host-only rejections; true => the call's value is +inf without touching the device.
 bool rejected(const cafe_ctx* c, const cafe_params* pr, int K) {
@@ -477,44 +445,11 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bo
         return CAFE_OK;
     }
 
-    // ---- matrix keys: one slot per distinct (lambda_q, t_q) and layout; de-quantized like matrix_cache.cpp:148-149
-    char* st = c->h_stage;
-    SlotParam* h_slots = reinterpret_cast<SlotParam*>(st);
-    SlotParam* h_kslots = h_slots + c->max_slots;
-    std::map<std::pair<long, long>, int> key_slot[2];
-    int n_slots = 0, n_kslots = 0;
-    for (int v = 0; v < c->n_nodes; ++v) {
-        if (v == c->root) continue;
-        const int layout = c->leaf_taxon[v] >= 0 ? 0 : 1;
-        for (int k = 0; k < K; ++k) {
-            const double mult = gamma ? pr->multipliers[k] : 1.0;
-            const double lam = pr->lambdas[c->lam_idx[v]] * mult;               // lambda.h:39, :82-88
-            long lq, tq;
-            quantize(lam, c->blen[v], &lq, &tq);
-            auto key = std::make_pair(tq, lq);
-            auto it = key_slot[layout].find(key);
-            int slot;
-            if (it == key_slot[layout].end()) {
-                slot = layout ? n_kslots++ : n_slots++;
-                key_slot[layout].emplace(key, slot);
-                const double lambda_q = double(lq) / 1000000000.0, t_q = double(tq) / 1000.0;
-                const double alpha = lambda_q * t_q / (1 + lambda_q * t_q);
-                const double coeff = 1 - 2 * alpha;
-                SlotParam sp;
-                sp.alpha = alpha;
-                sp.oma2 = (1 - alpha) * (1 - alpha);
-                sp.zero = !(coeff > 0 && coeff != 1);       // saturated (coeff < 0) or degenerate: rows s>=1 are 0
-                sp.pad = 0;
-                (layout ? h_kslots : h_slots)[slot] = sp;
-            } else {
-                slot = it->second;
-            }
-            c->slot_of[(size_t)v * c->Kmax + k] = slot;
-        }
+    {
+        const int rc = prepare_matrices(c, pr->lambdas, gamma ? pr->multipliers : nullptr, K, s);
+        if (rc != CAFE_OK) return rc;
     }
-    c->n_slots_last = n_slots;
-    c->n_kslots_last = n_kslots;
-    c->stats.n_matrices = n_slots + n_kslots;
+    char* st = c->h_stage;
     size_t off = sizeof(SlotParam) * (size_t)(c->max_slots + c->max_kslots);
     double* h_prior = reinterpret_cast<double*>(st + off); off += sizeof(double) * c->R;
     double* h_logprior = reinterpret_cast<double*>(st + off); off += sizeof(double) * c->R;
@@ -526,8 +461,6 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bo
         h_logprior[j] = std::log(eq);
     }
     for (int k = 0; k < K; ++k) h_cat[k] = gamma ? pr->cat_probs[k] : 1.0;
-    if (n_slots) HIP_TRY(c, hipMemcpyAsync(c->d_slots, h_slots, sizeof(SlotParam) * n_slots, hipMemcpyHostToDevice, s));
-    if (n_kslots) HIP_TRY(c, hipMemcpyAsync(c->d_slots + c->max_slots, h_kslots, sizeof(SlotParam) * n_kslots, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->d_prior, h_prior, sizeof(double) * c->R, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->d_logprior, h_logprior, sizeof(double) * c->R, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->d_catprobs, h_cat, sizeof(double) * K, hipMemcpyHostToDevice, s));
@@ -539,11 +472,6 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bo
     HIP_TRY(c, hipEventRecord(c->ev_upload, s));
     c->upload_pending = true;
 
-    // ---- K1
-    if (c->profile) HIP_TRY(c, hipEventRecord(c->ev[0], s));
-    HIP_TRY(c, launch_bd_matrix_build(c->pool, c->d_slots, n_slots, s));
-    HIP_TRY(c, launch_bd_matrix_build(c->kpool, c->d_slots + c->max_slots, n_kslots, s));
-    if (c->profile) HIP_TRY(c, hipEventRecord(c->ev[1], s));
 
     // ---- prune, chunk by chunk
     c->gemm_ev_used = 0;
@@ -754,6 +682,26 @@ int cafe_root_max(cafe_ctx* ctx, const cafe_params* params, double* out) {
     HIP_TRY(ctx, hipMemcpy(tmp.data(), ctx->d_fam_out, sizeof(double) * ctx->F_uniq, hipMemcpyDeviceToHost));
     for (int64_t f = 0; f < ctx->F_all; ++f) out[f] = tmp[ctx->ref_of[f]];
     return CAFE_OK;
+}
+
+int cafe_reconstruct(cafe_ctx* ctx, const cafe_params* params, const float* root_prior, int32_t* states) {
+    if (!ctx) return CAFE_ERR_ARGUMENT;
+    try {
+        return reconstruct_impl(ctx, params, root_prior, states);
+    } catch (const std::exception& e) {
+        set_err(ctx, "cafe_reconstruct: %s", e.what());
+        return CAFE_ERR_MEMORY;
+    }
+}
+
+int cafe_branch_probabilities(cafe_ctx* ctx, const cafe_params* params, const int32_t* sizes, double* out) {
+    if (!ctx) return CAFE_ERR_ARGUMENT;
+    try {
+        return branch_probabilities_impl(ctx, params, sizes, out);
+    } catch (const std::exception& e) {
+        set_err(ctx, "cafe_branch_probabilities: %s", e.what());
+        return CAFE_ERR_MEMORY;
+    }
 }
 
 int cafe_matrix_size(const cafe_ctx* ctx) { return ctx ? ctx->N : 0; }

@@ -148,6 +148,19 @@ int cafe_family_results(cafe_ctx* ctx, const cafe_family_out* out);
  * read.  out[n_families].  cafe_family_results is not meaningful after this call. */
 int cafe_root_max(cafe_ctx* ctx, const cafe_params* params, double* out);
 
+/* Ancestral reconstruction.  Pupko's joint reconstruction as reconstruct_gene_family runs it
+ * (gene_family_reconstructor.cpp:13-165; base_model.cpp:145, gamma_core.cpp:301): for every category k (one for
+ * the base model; lambda * multipliers[k] for the gamma model) and family f, the reconstructed size of every node
+ * -> states[k][f][node] (leaves carry their observed counts).  root_prior[j] = root_equilibrium_distribution::
+ * compute(j) for j = 0..min(M,R) (one more entry than params->prior: the root scan of :47-62 reads compute(j) with
+ * j as the SIZE, up to min(M,R) inclusive).  No error model is applied (:28-32 read the matrix column of the
+ * observed count).  params: model, lambdas, n_categories, multipliers. */
+int cafe_reconstruct(cafe_ctx* ctx, const cafe_params* params, const float* root_prior, int32_t* states);
+/* compute_viterbi_sum (gene_family_reconstructor.cpp:361-400) for every family and node under the plain lambdas:
+ * sizes[f][node] are the (reconstructed / observed) sizes, out[f][node] the branch probability, NaN where the
+ * reference returns "invalid" (the root; parent size == child size). */
+int cafe_branch_probabilities(cafe_ctx* ctx, const cafe_params* params, const int32_t* sizes, double* out);
+
 /* Introspection for parity tests: the transition matrix the last call built for the branch above
  * `node` in category k (N x N row-major, N = max(M,R)+1: matrix_cache::get_matrix; for an interior
  * branch the columns c > M, which the prune never reads, are not materialised and come back 0), and the root

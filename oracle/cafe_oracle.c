@@ -598,6 +598,128 @@ void orc_tree_pvalues(const double* observed, int64_t F, const double* cond, int
     }
 }
 
+/* ---------------------------------------------------------------------------------
+ * Pupko joint reconstruction: gene_family_reconstructor.cpp:13-165 (per family), called once per family by
+ * base_model.cpp:145-160 and once per family and category (lambda * multiplier) by gamma_core.cpp:301-345.
+ * root_prior[j] = root_equilibrium_distribution::compute(j), j = 0..min(M,R).
+ * states[k][f][node]; leaves carry the observed count.
+ * --------------------------------------------------------------------------------- */
+static int reconstruct_one(const orc_problem* pb, const orc_params* pr, const mat_cache* cache, const int32_t* counts_row, double mult,
+                           const float* root_prior, double* L, int* C, int32_t* state) {
+    const orc_tree* tr = &pb->tree;
+    int M = pb->max_family_size, R = pb->max_root_family_size, n = cache->n;
+    int len = M + 1;
+    int root = root_of(tr);
+    for (int v = 0; v < tr->n_nodes; ++v) {                         /* apply_reverse_level_order: children first */
+        double* Lv = L + (size_t)v * len;
+        int* Cv = C + (size_t)v * len;
+        if (tr->leaf_taxon[v] >= 0) {                               /* reconstruct_leaf_node :13-33 */
+            int x = counts_row[tr->leaf_taxon[v]];
+            double lam = pr->lambdas[tr->lambda_index ? tr->lambda_index[v] : 0] * mult;
+            const double* mat = cache_get(cache, tr->branch_length[v], lam);
+            if (!mat) return -1;
+            Lv[0] = 0.0;                                            /* the loop starts at i = 1 */
+            for (int i = 1; i < len; ++i) Lv[i] = mat[(size_t)i * n + x];
+            for (int i = 0; i < len; ++i) Cv[i] = x;
+            continue;
+        }
+        if (v == root) {                                            /* reconstruct_root_node :35-70 */
+            int lr = (M < R ? M : R) + 1;
+            double max_val = -1;
+            Cv[0] = 0;
+            for (int j = 1; j < lr; ++j) {                          /* the same scan for every i: done once */
+                double value = 1.0;
+                for (int u = 0; u < tr->n_nodes; ++u) if (tr->parent[u] == v) value *= L[(size_t)u * len + j];
+                double val = value * root_prior[j];
+                if (val > max_val) { max_val = val; Cv[0] = j; }
+            }
+            continue;
+        }
+        double lam = pr->lambdas[tr->lambda_index ? tr->lambda_index[v] : 0] * mult;
+        const double* mat = cache_get(cache, tr->branch_length[v], lam);
+        if (!mat) return -1;
+        for (int i = 0; i < len; ++i) {                             /* reconstruct_internal_node :72-113 */
+            int max_j = 0;
+            double max_val = -1;
+            for (int j = 0; j < len; ++j) {
+                double value = 1.0;
+                for (int u = 0; u < tr->n_nodes; ++u) if (tr->parent[u] == v) value *= L[(size_t)u * len + j];
+                double val = value * mat[(size_t)i * n + j];
+                if (val > max_val) { max_j = j; max_val = val; }
+            }
+            Lv[i] = max_val;
+            Cv[i] = max_j;
+        }
+    }
+    state[root] = C[(size_t)root * len];                            /* :161-163 and the backtracker :147-155 */
+    for (int v = tr->n_nodes - 1; v >= 0; --v) {                    /* parents before children */
+        if (v == root) continue;
+        if (tr->leaf_taxon[v] >= 0) { state[v] = counts_row[tr->leaf_taxon[v]]; continue; }
+        state[v] = C[(size_t)v * len + state[tr->parent[v]]];
+    }
+    return 0;
+}
+
+int orc_reconstruct(const orc_problem* pb, const orc_params* pr, const float* root_prior, int32_t* states) {
+    if (!lambdas_valid(pb, pr)) return 1;
+    int K = pr->n_categories;
+    double one = 1.0;
+    const double* mults = (K > 1 || pr->multipliers) ? pr->multipliers : &one;
+    mat_cache cache;
+    if (build_all(pb, pr, mults, K, &cache)) return 2;
+    int len = pb->max_family_size + 1, nn = pb->tree.n_nodes;
+    int64_t F = pb->n_families;
+    int failed = 0;
+#pragma omp parallel
+    {
+        double* L = (double*)malloc(sizeof(double) * (size_t)len * nn);
+        int* C = (int*)malloc(sizeof(int) * (size_t)len * nn);
+#pragma omp for schedule(dynamic, 4) collapse(2)
+        for (int k = 0; k < K; ++k)
+            for (int64_t f = 0; f < F; ++f)
+                if (reconstruct_one(pb, pr, &cache, pb->counts + f * pb->n_taxa, mults[k], root_prior, L, C, states + ((size_t)k * F + f) * nn)) {
+#pragma omp atomic write
+                    failed = 1;
+                }
+        free(L); free(C);
+    }
+    cache_free(&cache);
+    return failed ? 3 : 0;
+}
+
+/* compute_viterbi_sum, gene_family_reconstructor.cpp:361-400, for every family and node under the plain lambdas;
+ * sizes[f][node]; NaN where the reference returns an invalid branch_probability */
+int orc_branch_probabilities(const orc_problem* pb, const orc_params* pr, const int32_t* sizes, double* out) {
+    if (!lambdas_valid(pb, pr)) return 1;
+    const orc_tree* tr = &pb->tree;
+    double one = 1.0;
+    mat_cache cache;
+    if (build_all(pb, pr, &one, 1, &cache)) return 2;
+    int nn = tr->n_nodes, n = cache.n, M = pb->max_family_size;
+    for (int64_t f = 0; f < pb->n_families; ++f)
+        for (int v = 0; v < nn; ++v) {
+            double res = NAN;
+            if (tr->parent[v] >= 0) {
+                int ps = sizes[f * nn + tr->parent[v]], cs = sizes[f * nn + v];
+                if (ps != cs) {
+                    double lam = pr->lambdas[tr->lambda_index ? tr->lambda_index[v] : 0];
+                    const double* mat = cache_get(&cache, tr->branch_length[v], lam);
+                    if (!mat) { cache_free(&cache); return 3; }
+                    double calc = mat[(size_t)ps * n + cs];
+                    res = 0;
+                    for (int m = 0; m < M; m++) {
+                        double pm = mat[(size_t)ps * n + m];
+                        if (pm == calc) res += pm / 2.0;
+                        else if (pm < calc) res += pm;
+                    }
+                }
+            }
+            out[f * nn + v] = res;
+        }
+    cache_free(&cache);
+    return 0;
+}
+
 /* gamma_core.cpp:123-246 */
 double orc_score_gamma(const orc_problem* pb, const orc_params* pr, double* cat_lik, double* fam_lik) {
     double t_start = now_s();

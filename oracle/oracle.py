@@ -84,6 +84,10 @@ def lib():
         L.orc_num_threads.restype = C.c_int
         L.orc_last_timings.argtypes = [_f64p, _f64p]
         L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_reconstruct.restype = C.c_int
+        L.orc_reconstruct.argtypes = [C.POINTER(_Problem), C.POINTER(_Params), _f32p, _i32p]
+        L.orc_branch_probabilities.restype = C.c_int
+        L.orc_branch_probabilities.argtypes = [C.POINTER(_Problem), C.POINTER(_Params), _i32p, _f64p]
         L.orc_root_max.restype = C.c_int
         L.orc_root_max.argtypes = [C.POINTER(_Problem), C.POINTER(_Params), _f64p]
         L.orc_pvalue.restype = C.c_double
@@ -224,6 +228,38 @@ def root_max(pb, lambdas, fast: bool = False) -> np.ndarray:
     rc = lib().orc_root_max(C.byref(b.pb), C.byref(b.pr), _p(out, _f64p))
     if rc:
         raise RuntimeError("oracle: root_max failed (%d)" % rc)
+    return out
+
+
+def reconstruct(pb, lambdas, root_prior, multipliers=None, fast: bool = False) -> np.ndarray:
+    """Pupko joint reconstruction -> int32 [K][F][n_nodes] (gene_family_reconstructor.cpp:13-165)."""
+    from cafexp_amd.problem import Params
+    pr = Params(lambdas=np.asarray(lambdas, dtype=np.float64), prior=np.ones(pb.max_root_family_size, dtype=np.float32))
+    K = 1
+    if multipliers is not None:
+        pr.multipliers = np.asarray(multipliers, dtype=np.float64)
+        pr.cat_probs = np.full(len(pr.multipliers), 1.0 / len(pr.multipliers))
+        K = len(pr.multipliers)
+    b = _Bound(pb, pr, fast)
+    rp = np.ascontiguousarray(root_prior, dtype=np.float32)
+    assert len(rp) >= min(pb.max_family_size, pb.max_root_family_size) + 1
+    out = np.empty((K, pb.n_families, pb.n_nodes), dtype=np.int32)
+    rc = lib().orc_reconstruct(C.byref(b.pb), C.byref(b.pr), _p(rp, _f32p), _p(out, _i32p))
+    if rc:
+        raise RuntimeError("oracle: reconstruct failed (%d)" % rc)
+    return out
+
+
+def branch_probabilities(pb, lambdas, sizes, fast: bool = False) -> np.ndarray:
+    """compute_viterbi_sum for every (family, node); NaN = invalid (gene_family_reconstructor.cpp:361-400)."""
+    from cafexp_amd.problem import Params
+    pr = Params(lambdas=np.asarray(lambdas, dtype=np.float64), prior=np.ones(pb.max_root_family_size, dtype=np.float32))
+    b = _Bound(pb, pr, fast)
+    sz = np.ascontiguousarray(sizes, dtype=np.int32)
+    out = np.empty((pb.n_families, pb.n_nodes), dtype=np.float64)
+    rc = lib().orc_branch_probabilities(C.byref(b.pb), C.byref(b.pr), _p(sz, _i32p), _p(out, _f64p))
+    if rc:
+        raise RuntimeError("oracle: branch_probabilities failed (%d)" % rc)
     return out
 
 

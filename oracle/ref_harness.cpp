@@ -19,6 +19,10 @@
 //             [errfile=] [prior=uniform|poisson:X] [rootdist=file] [rootfilter=1] [limit=N]
 //             [m= r=]  -> -lnL, per-family table, wall seconds
 //   time_matrices n= lambda= count= t0=          wall seconds of precalculate_matrices for `count` branch lengths
+//   reconstruct tree= families= [lambda=|lambdas= lambda_tree=] [model=gamma k= alpha=] [errfile=] [prior=] [limit=] [m= r=]
+//             [nsim= seed= pvalue=0.05 files=1]   the tail of estimator::execute (execute.cpp:147-180): infer once,
+//             [compute_pvalues,] reconstruct_ancestral_states, compute_viterbi_sum for every family and node;
+//             files=1 adds the text of every report reconstruction::write_results writes
 //   pvalues   tree= families= lambda=|lambdas= lambda_tree= [nsim=1000] [seed=10] [ncond=0] [limit=] [m= r=]
 //             compute_pvalues at a fixed seed of the global engine; ncond > 0 also prints the sorted conditional
 //             distributions get_random_probabilities returns for root sizes 0..ncond-1 (same seed, same order)
@@ -49,6 +53,7 @@
 #include "src/lambda.h"
 #include "src/error_model.h"
 #include "src/gene_family.h"
+#include "src/gene_family_reconstructor.h"
 
 std::mt19937 randomizer_engine(10);   // main.cpp:3 / test.cpp:35 define this global
 void init_lgamma_cache();             // probability.cpp:66
@@ -279,6 +284,126 @@ static int job_pvalues(const kv_t& kv) {
     return 0;
 }
 
+static std::string json_escape(const std::string& t) {
+    std::string o;
+    for (char ch : t) {
+        if (ch == '\n') o += "\\n"; else if (ch == '\t') o += "\\t"; else if (ch == '"') o += "\\\""; else if (ch == '\\') o += "\\\\"; else o += ch;
+    }
+    return o;
+}
+
+static int job_reconstruct(const kv_t& kv) {
+    input_parameters p;
+    p.tree_file_path = gets(kv, "tree");
+    p.input_file_path = gets(kv, "families");
+    if (has(kv, "lambda")) p.fixed_lambda = getd(kv, "lambda");
+    if (has(kv, "lambdas")) { p.fixed_multiple_lambdas = gets(kv, "lambdas"); p.lambda_tree_file_path = gets(kv, "lambda_tree"); }
+    if (has(kv, "errfile")) { p.use_error_model = true; p.error_model_file_path = gets(kv, "errfile"); }
+    user_data d;
+    d.read_datafiles(p);
+    if (geti(kv, "rootfilter", 1)) {
+        auto rem = std::remove_if(d.gene_families.begin(), d.gene_families.end(), [&](const gene_family& fam) {
+            return !fam.exists_at_root(d.p_tree); });
+        d.gene_families.erase(rem, d.gene_families.end());
+    }
+    if (has(kv, "limit")) {
+        size_t lim = (size_t)geti(kv, "limit");
+        if (d.gene_families.size() > lim) d.gene_families.resize(lim);
+    }
+    if (has(kv, "m")) d.max_family_size = geti(kv, "m");
+    if (has(kv, "r")) d.max_root_family_size = geti(kv, "r");
+    std::unique_ptr<root_equilibrium_distribution> prior;
+    std::string prs = gets(kv, "prior", "uniform");
+    if (prs == "uniform") prior.reset(new uniform_distribution());
+    else prior.reset(new ::poisson_distribution(std::stod(prs.substr(prs.find(':') + 1))));
+    std::string mdl = gets(kv, "model", "base");
+    std::unique_ptr<model> m;
+    if (mdl == "gamma")
+        m.reset(new gamma_model(d.p_lambda, d.p_tree, &d.gene_families, d.max_family_size, d.max_root_family_size, geti(kv, "k"), getd(kv, "alpha"), d.p_error_model));
+    else
+        m.reset(new base_model(d.p_lambda, d.p_tree, &d.gene_families, d.max_family_size, d.max_root_family_size, d.p_error_model));
+    const double test_pvalue = getd(kv, "pvalue", 0.05);
+    const int nsim = geti(kv, "nsim", 0);
+
+    double score = m->infer_family_likelihoods(prior.get(), d.rootdist, d.p_lambda);       // compute(), execute.cpp:49
+    matrix_cache cache(std::max(d.max_family_size, d.max_root_family_size) + 1);             // execute.cpp:157-158
+    cache.precalculate_matrices(get_lambda_values(m->get_lambda()), d.p_tree->get_branch_lengths());
+    std::vector<double> pvalues(d.gene_families.size(), 1.0);
+    if (nsim > 0) {
+        randomizer_engine.seed(geti(kv, "seed", 10));
+        pvalues = compute_pvalues(d.p_tree, d.gene_families, m->get_lambda(), cache, nsim, d.max_family_size, d.max_root_family_size);
+    }
+    double t0 = now();
+    std::unique_ptr<reconstruction> rec(m->reconstruct_ancestral_states(d.gene_families, &cache, prior.get()));
+    double dt = now() - t0;
+
+    cladevector order;
+    d.p_tree->apply_reverse_level_order([&order](const clade* c) { order.push_back(c); });
+    branch_probabilities probs;                                                              // execute.cpp:165-176
+    for (size_t i = 0; i < d.gene_families.size(); ++i)
+        if (pvalues[i] < test_pvalue)
+            for (auto c : order) probs.set(d.gene_families[i], c, compute_viterbi_sum(c, d.gene_families[i], rec.get(), d.max_family_size, cache, m->get_lambda()));
+
+    printf("{\"neg_lnl\": "); pd(score);
+    printf(", \"n_families\": %zu, \"max_family_size\": %d, \"max_root_family_size\": %d, \"seconds\": %.6f, \"threads\": %d, \"nodes\": [",
+        d.gene_families.size(), d.max_family_size, d.max_root_family_size, dt, omp_get_max_threads());
+    for (size_t i = 0; i < order.size(); ++i) printf("%s\"%s\"", i ? ", " : "", order[i]->get_taxon_name().c_str());
+    printf("], \"states\": [");
+    bool first = true;
+    for (auto& gf : d.gene_families)
+        for (auto c : order) { printf("%s%d", first ? "" : ",", rec->reconstructed_size(gf, c)); first = false; }
+    printf("]");
+    if (auto g = dynamic_cast<gamma_model_reconstruction*>(rec.get())) {
+        printf(", \"category_states\": [");       // [family][category][node]
+        first = true;
+        for (auto& gf : d.gene_families) {
+            auto& r = g->_reconstructions.at(gf.id());
+            for (auto& cat : r.category_reconstruction)
+                for (auto c : order) {
+                    int v = c->is_leaf() ? gf.get_species_size(c->get_taxon_name()) : cat.at(c);
+                    printf("%s%d", first ? "" : ",", v); first = false;
+                }
+        }
+        printf("], \"averages\": [");             // [family][node], the weighted averages before rounding
+        first = true;
+        for (auto& gf : d.gene_families) {
+            auto& r = g->_reconstructions.at(gf.id());
+            for (auto c : order) {
+                double v = c->is_leaf() ? gf.get_species_size(c->get_taxon_name()) : r.reconstruction.at(c);
+                printf("%s", first ? "" : ","); pd(v); first = false;
+            }
+        }
+        printf("]");
+    }
+    std::vector<double> bp;
+    for (auto& gf : d.gene_families)
+        for (auto c : order) {
+            auto r = compute_viterbi_sum(c, gf, rec.get(), d.max_family_size, cache, m->get_lambda());
+            bp.push_back(r._is_valid ? r._value : NAN);
+        }
+    printf(", "); parr("branch_probabilities", bp);
+    if (nsim > 0) { printf(", "); parr("pvalues", pvalues); }
+    if (geti(kv, "files", 0)) {
+        std::ostringstream asr, count, change, famres, clres, bpf;
+        rec->print_reconstructed_states(asr, order, d.gene_families, d.p_tree, test_pvalue, probs);
+        rec->print_node_counts(count, order, d.gene_families, d.p_tree);
+        rec->print_node_change(change, order, d.gene_families, d.p_tree);
+        rec->print_increases_decreases_by_family(famres, order, d.gene_families, pvalues, test_pvalue);
+        rec->print_increases_decreases_by_clade(clres, order, d.gene_families);
+        print_branch_probabilities(bpf, order, d.gene_families, probs);
+        printf(", \"asr_tre\": \"%s\", \"count_tab\": \"%s\", \"change_tab\": \"%s\", \"family_results_txt\": \"%s\", \"clade_results_txt\": \"%s\", \"branch_probabilities_tab\": \"%s\"",
+            json_escape(asr.str()).c_str(), json_escape(count.str()).c_str(), json_escape(change.str()).c_str(), json_escape(famres.str()).c_str(),
+            json_escape(clres.str()).c_str(), json_escape(bpf.str()).c_str());
+        if (auto g = dynamic_cast<gamma_model_reconstruction*>(rec.get())) {
+            std::ostringstream cl;
+            g->print_category_likelihoods(cl, order, d.gene_families);
+            printf(", \"category_likelihoods_txt\": \"%s\"", json_escape(cl.str()).c_str());
+        }
+    }
+    printf("}\n");
+    return 0;
+}
+
 static int job_time_matrices(const kv_t& kv) {
     int n = geti(kv, "n"), count = geti(kv, "count", 1);
     double lambda = getd(kv, "lambda"), t0v = getd(kv, "t0", 1.0);
@@ -308,6 +433,7 @@ int main(int argc, char** argv) {
         if (job == "score") return job_score(kv);
         if (job == "time_matrices") return job_time_matrices(kv);
         if (job == "pvalues") return job_pvalues(kv);
+        if (job == "reconstruct") return job_reconstruct(kv);
     } catch (std::exception& e) {
         fprintf(stderr, "ref_harness: %s\n", e.what());
         return 1;

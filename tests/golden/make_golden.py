@@ -74,7 +74,36 @@ def make_pvalues():
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def make_reconstruct():
+    """tests/golden/ref_reconstruct.json: the tail of estimator::execute on the real reference (SURVEY 8f-4): Pupko
+    reconstruction, Viterbi branch probabilities, and (files=1) the text of every report write_results produces."""
+    data = lambda n: os.path.join(D, n)
+    T, F = data("mammals_tree.txt"), data("mammal_gene_families.txt")
+    jobs = {
+        "mammals_base": dict(tree=T, families=F, limit=150, nsim=100, seed=10, files=1, **{"lambda": 0.0018174300635539}),
+        "mammals_gamma_k3": dict(tree=T, families=F, limit=80, nsim=50, seed=4, files=1, model="gamma", k=3, alpha=0.6, **{"lambda": 0.002}),
+        "mammals_lambda_tree": dict(tree=T, families=F, limit=100, lambdas="0.01,0.05", lambda_tree=data("chimphuman_separate_lambda.txt")),
+        "mammals_poisson": dict(tree=T, families=F, limit=60, prior="poisson:10", **{"lambda": 0.01}),
+        "synth20": dict(tree=data("synth20_tree.txt"), families=data("synth20_families.txt"), **{"lambda": 0.004}),
+    }
+    out = {"generator": "tests/golden/make_golden.py reconstruct", "source": "oracle/_ref/ref_harness reconstruct (real reference)", "cases": {}}
+    for name, kv in jobs.items():
+        print("ref reconstruct:", name, flush=True)
+        r = O.ref("reconstruct", **kv)
+        e = {"args": {k: (os.path.basename(v) if isinstance(v, str) and os.sep in v else v) for k, v in kv.items()}}
+        e.update(r)
+        out["cases"][name] = e
+    path = os.path.join(HERE, "ref_reconstruct.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0, separators=(",", ":"))
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 def main():
+    if sys.argv[1:] == ["reconstruct"]:
+        if not O.have_ref():
+            raise SystemExit("oracle/_ref/ref_harness missing: run `make -C oracle ref` in the build container")
+        return make_reconstruct()
     if sys.argv[1:] == ["pvalues"]:
         if not O.have_ref():
             raise SystemExit("oracle/_ref/ref_harness missing: run `make -C oracle ref` in the build container")

@@ -1,0 +1,181 @@
+"""Ancestral reconstruction (src/gene_family_reconstructor.cpp:13-165, :361-400).
+
+Golden values: tests/golden/ref_reconstruct.json, printed by the compiled reference running the tail of
+estimator::execute (tests/golden/make_golden.py reconstruct).
+CPU: the oracle's restatement against those.  GPU: cafe_reconstruct / cafe_branch_probabilities through the C ABI
+against the oracle and the golden values.  States are integers: exact, except that an arg max between two candidates
+whose products agree to rounding may fall either way (the matrices come from a different but equivalent recurrence);
+such a difference must be a near-tie in likelihood, which the test checks.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import case_from_args
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gr():
+    with open(os.path.join(ROOT, "tests", "golden", "ref_reconstruct.json")) as f:
+        return json.load(f)["cases"]
+
+
+def _case(e):
+    pb, pr, alpha = case_from_args(e["args"], O)
+    assert (pb.n_families, pb.max_family_size, pb.max_root_family_size) == (e["n_families"], e["max_family_size"], e["max_root_family_size"])
+    jmax = min(pb.max_family_size, pb.max_root_family_size)
+    rp = np.zeros(jmax + 1, dtype=np.float32)                     # compute(j) is 0 past the R entries of the prior
+    n = min(len(pr.prior), jmax + 1)
+    rp[:n] = pr.prior[:n]
+    perm = [pb.node_names.index(name) for name in e["nodes"]]    # golden node order (reverse level order) -> ours
+    return pb, pr, rp, perm
+
+
+def _golden_states(e, perm, n_nodes):
+    g = np.array(e["states"], dtype=np.int64).reshape(e["n_families"], len(perm))
+    out = np.empty((e["n_families"], n_nodes), dtype=np.int64)
+    out[:, perm] = g
+    return out
+
+
+def _golden_cat_states(e, perm, n_nodes, K):
+    g = np.array(e["category_states"], dtype=np.int64).reshape(e["n_families"], K, len(perm))
+    out = np.empty((K, e["n_families"], n_nodes), dtype=np.int64)
+    for k in range(K):
+        out[k][:, perm] = g[:, k, :]
+    return out
+
+
+def _golden_bp(e, perm, n_nodes):
+    g = np.array(e["branch_probabilities"], dtype=np.float64).reshape(e["n_families"], len(perm))
+    out = np.empty((e["n_families"], n_nodes))
+    out[:, perm] = g
+    return out
+
+
+def _check_bp(got, want, tol):
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    m = ~np.isnan(want)
+    assert np.max(np.abs(got[m] - want[m]) / np.maximum(np.abs(want[m]), 1e-300)) < tol
+
+
+CASES = ["mammals_base", "mammals_gamma_k3", "mammals_lambda_tree", "mammals_poisson", "synth20"]
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reconstruction_matches_reference(gr, name):
+    e = gr[name]
+    pb, pr, rp, perm = _case(e)
+    if pr.multipliers is not None:
+        got = O.reconstruct(pb, pr.lambdas, rp, multipliers=pr.multipliers)
+        assert np.array_equal(got, _golden_cat_states(e, perm, pb.n_nodes, len(pr.multipliers)))
+        # weighted averages (gamma_core.cpp:283-299) and the reported integer sizes (:407-420: truncation)
+        avg = np.zeros((pb.n_families, pb.n_nodes))
+        for k in range(len(pr.multipliers)):
+            avg += pr.cat_probs[k] * got[k].astype(np.float64)
+        want_avg = np.empty_like(avg)
+        want_avg[:, perm] = np.array(e["averages"]).reshape(pb.n_families, len(perm))
+        assert np.max(np.abs(avg - want_avg)) < 1e-9
+    else:
+        got = O.reconstruct(pb, pr.lambdas, rp)
+        assert np.array_equal(got[0], _golden_states(e, perm, pb.n_nodes))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_branch_probabilities_match_reference(gr, name):
+    e = gr[name]
+    pb, pr, rp, perm = _case(e)
+    sizes = _golden_states(e, perm, pb.n_nodes)
+    got = O.branch_probabilities(pb, pr.lambdas, sizes)
+    _check_bp(got, _golden_bp(e, perm, pb.n_nodes), 1e-11)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+def _near_tie_only(pb, pr, rp, got, want, mult):
+    """Every family whose reconstruction differs from the reference's must be a rounding-level tie: both joint
+    assignments have the same likelihood to 1e-9 (the reference's own argmax scans decide by the last bits)."""
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert len(bad) <= max(1, len(got) // 200), "%d of %d families differ" % (len(bad), len(got))
+    for f in bad:
+        la, lb = (_joint_likelihood(pb, pr, rp, s[f], mult) for s in (got, want))
+        assert abs(la - lb) <= 1e-9 * max(la, lb), (f, la, lb)
+
+
+def _joint_likelihood(pb, pr, rp, state, mult):
+    lik = float(rp[state[np.nonzero(pb.parent < 0)[0][0]]])
+    for v in range(pb.n_nodes):
+        par = pb.parent[v]
+        if par < 0:
+            continue
+        lam = pr.lambdas[pb.lambda_index[v]] * mult
+        if state[par] == 0:
+            lik *= 1.0 if state[v] == 0 else 0.0
+        else:
+            lik *= O.bd_prob(*O.quantize(lam, pb.branch_length[v]), int(state[par]), int(state[v]))
+    return lik
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_reconstruction_matches_reference(gr, name):
+    from cafexp_amd import capi
+    e = gr[name]
+    pb, pr, rp, perm = _case(e)
+    ctx = capi.Context(pb, max_categories=1 if pr.multipliers is None else len(pr.multipliers))
+    if pr.multipliers is not None:
+        got = ctx.reconstruct(pr.lambdas, rp, multipliers=pr.multipliers)
+        want = _golden_cat_states(e, perm, pb.n_nodes, len(pr.multipliers))
+        for k in range(len(pr.multipliers)):
+            _near_tie_only(pb, pr, rp, got[k], want[k], pr.multipliers[k])
+    else:
+        got = ctx.reconstruct(pr.lambdas, rp)
+        assert got.shape == (1, pb.n_families, pb.n_nodes)
+        _near_tie_only(pb, pr, rp, got[0], _golden_states(e, perm, pb.n_nodes), 1.0)
+    # leaves carry the observed counts
+    leaves = np.nonzero(pb.leaf_taxon >= 0)[0]
+    assert np.array_equal(got[0][:, leaves], pb.counts[:, pb.leaf_taxon[leaves]])
+    # the scorer path still works on the same context afterwards
+    assert np.isfinite(ctx.score(pr)) or pr.multipliers is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_branch_probabilities_match_reference(gr, name):
+    from cafexp_amd import capi
+    e = gr[name]
+    pb, pr, rp, perm = _case(e)
+    ctx = capi.Context(pb)
+    sizes = _golden_states(e, perm, pb.n_nodes)
+    got = ctx.branch_probabilities(pr.lambdas, sizes)
+    _check_bp(got, _golden_bp(e, perm, pb.n_nodes), 1e-9)
+
+
+@pytest.mark.gpu
+def test_reconstruction_chunked_and_duplicated_families(gr):
+    """A small workspace forces several column chunks; duplicated families share one device column."""
+    from cafexp_amd import capi
+    e = gr["synth20"]
+    pb, pr, rp, perm = _case(e)
+    pb.counts = np.ascontiguousarray(np.concatenate([pb.counts, pb.counts[::3]]))
+    pb.family_ids = pb.family_ids + ["dup%d" % i for i in range(len(pb.counts) - len(pb.family_ids))]
+    ctx = capi.Context(pb)
+    got = ctx.reconstruct(pr.lambdas, rp)[0]
+    want = O.reconstruct(pb, pr.lambdas, rp)[0]
+    _near_tie_only(pb, pr, rp, got, want, 1.0)
+
+
+@pytest.mark.gpu
+def test_reconstruct_argument_errors(gr):
+    from cafexp_amd import capi
+    pb, pr, rp, perm = _case(gr["synth20"])
+    ctx = capi.Context(pb)
+    with pytest.raises(capi.CafeError):
+        ctx.reconstruct(np.array([-1.0]), rp)
+    with pytest.raises(capi.CafeError):
+        ctx.branch_probabilities(pr.lambdas, np.full((pb.n_families, pb.n_nodes), pb.max_family_size + 1))
