@@ -52,6 +52,7 @@ public:
     void validate_lambda_tree(const clade* lambda_tree) const;      // clade.cpp:207
     void apply_prefix_order(const std::function<void(const clade*)>& f) const;
     void apply_reverse_level_order(const std::function<void(const clade*)>& f) const;   // children before parents
+    void write_newick(std::ostream& ost, const std::function<std::string(const clade*)>& textwriter) const;   // clade.cpp:166
     std::vector<const clade*> post_order() const;                    // children before parents, root last
     std::vector<const clade*> leaves() const;
 
@@ -203,6 +204,7 @@ public:
 
 class inference_optimizer_scorer;
 struct user_data;
+class reconstruction;
 
 class model {
 protected:
@@ -224,6 +226,8 @@ public:
     virtual void write_family_likelihoods(std::ostream& ost) = 0;
     virtual void write_vital_statistics(std::ostream& ost, double final_likelihood);     // core.cpp:96
     virtual inference_optimizer_scorer* get_lambda_optimizer(user_data& data) = 0;
+    // core.h:177 without the matrix_cache argument (the device builds the matrices); default: not supported
+    virtual reconstruction* reconstruct_ancestral_states(const std::vector<gene_family>& families, root_equilibrium_distribution* p_prior);
     const std::vector<family_info_stash>& get_results() const { return results; }
     const event_monitor& get_monitor() const { return _monitor; }
     void initialize_lambda(const clade* lambda_tree);                // core.cpp:76
@@ -248,9 +252,17 @@ protected:
     void gather_call_inputs(root_equilibrium_distribution* prior, const std::map<int, int>& rootdist, std::vector<float>& prior_f,
                             std::vector<double>& err_table, std::vector<double>& lambdas) const;
 public:
+    // Pupko reconstruction on the device: states[k][family][index in _order] (cafe_reconstruct)
+    std::vector<int32_t> device_reconstruct(const std::vector<gene_family>& families, root_equilibrium_distribution* p_prior,
+                                            const std::vector<double>* multipliers);
+public:
     using model::model;
     ~hip_model_base() override;
     void set_device(int d) { _device = d; }
+    // compute_viterbi_sum (gene_family_reconstructor.cpp:361) for every family x node of `order` under the model's
+    // plain lambda: [family][order index], NaN where the reference returns an invalid branch_probability
+    std::vector<double> branch_probability_table(const reconstruction& rec, const std::vector<gene_family>& families,
+                                                 const std::vector<const clade*>& order);
 };
 class hip_base_model : public hip_model_base {
 public:
@@ -259,6 +271,7 @@ public:
     std::string name() const override { return "Base"; }
     void write_family_likelihoods(std::ostream& ost) override;
     inference_optimizer_scorer* get_lambda_optimizer(user_data& data) override;
+    reconstruction* reconstruct_ancestral_states(const std::vector<gene_family>& families, root_equilibrium_distribution* p_prior) override;   // base_model.cpp:145
 };
 class hip_gamma_model : public hip_model_base {
     std::vector<double> _lambda_multipliers, _gamma_cat_probs;
@@ -279,7 +292,93 @@ public:
     void write_vital_statistics(std::ostream& ost, double final_likelihood) override;   // + "Alpha:" (gamma_core.cpp:43)
     inference_optimizer_scorer* get_lambda_optimizer(user_data& data) override;
     const std::vector<std::vector<double>>& category_likelihoods() const { return _category_likelihoods; }
+    reconstruction* reconstruct_ancestral_states(const std::vector<gene_family>& families, root_equilibrium_distribution* p_prior) override;   // gamma_core.cpp:301
 };
+
+// ---------------------------------------------------------------- reconstruction reports (src/core.h:34-99,
+// src/gene_family_reconstructor.cpp:167-359, base_model.cpp:181-228, gamma_core.cpp:283-299, :347-432)
+typedef std::vector<const clade*> cladevector;
+std::string clade_index_or_name(const clade* node, const cladevector& order);                     // clade.cpp:185
+
+class branch_probabilities {
+public:
+    struct branch_probability {
+        bool _is_valid;
+        double _value;
+        branch_probability(double value) : _is_valid(true), _value(value) {
+            if (value < 0 || value > 1) throw std::runtime_error("Not a valid probability");
+        }
+        branch_probability() : _is_valid(false), _value(0.0) {}
+    };
+    bool contains(const gene_family& fam) const { return _probabilities.find(fam.id()) != _probabilities.end(); }
+    branch_probability at(const gene_family& fam, const clade* c) const { return _probabilities.at(fam.id()).at(c); }
+    void set(const gene_family& fam, const clade* c, branch_probability p) { _probabilities[fam.id()][c] = p; }
+    static branch_probability invalid() { return branch_probability(); }
+private:
+    std::map<std::string, std::map<const clade*, branch_probability>> _probabilities;
+};
+
+class reconstruction {
+public:
+    typedef const std::vector<gene_family> familyvector;
+    void print_node_change(std::ostream& ost, const cladevector& order, familyvector& gene_families, const clade* p_tree);
+    void print_node_counts(std::ostream& ost, const cladevector& order, familyvector& gene_families, const clade* p_tree);
+    void print_reconstructed_states(std::ostream& ost, const cladevector& order, familyvector& gene_families, const clade* p_tree, double test_pvalue,
+                                    const branch_probabilities& branch_probabilities);
+    // the reference walks a map keyed by node ADDRESS here, so its line order is an accident of the allocator;
+    // this writer lists the same lines in `order`
+    void print_increases_decreases_by_clade(std::ostream& ost, const cladevector& order, familyvector& gene_families);
+    void print_increases_decreases_by_family(std::ostream& ost, const cladevector& order, familyvector& gene_families, const std::vector<double>& pvalues,
+                                             double test_pvalue);
+    void print_family_clade_table(std::ostream& ost, const cladevector& order, familyvector& gene_families, const clade* p_tree,
+                                  const std::function<std::string(int family_index, const clade* c)>& get_family_clade_value);
+    void write_results(const std::string& model_identifier, const std::string& output_prefix, const clade* p_tree, familyvector& families,
+                       std::vector<double>& pvalues, double test_pvalue, const branch_probabilities& branch_probabilities);
+    virtual int reconstructed_size(const gene_family& family, const clade* clade) const = 0;
+    virtual ~reconstruction() {}
+private:
+    virtual void print_additional_data(const cladevector&, familyvector&, const std::string&) {}
+    virtual int get_difference_from_parent(const gene_family* gf, const clade* c) = 0;
+    virtual std::string get_reconstructed_state(const gene_family& gf, const clade* node) = 0;
+    virtual void write_nexus_extensions(std::ostream&) {}
+    virtual int get_node_count(const gene_family& gf, const clade* c) = 0;
+};
+void print_branch_probabilities(std::ostream& ost, const cladevector& order, const std::vector<gene_family>& gene_families,
+                                const branch_probabilities& branch_probabilities);
+
+class base_model_reconstruction : public reconstruction {
+public:
+    std::map<std::string, std::map<const clade*, int>> _reconstructions;
+    int reconstructed_size(const gene_family& family, const clade* clade) const override;
+private:
+    std::string get_reconstructed_state(const gene_family& gf, const clade* node) override;
+    int get_difference_from_parent(const gene_family* gf, const clade* c) override;
+    int get_node_count(const gene_family& gf, const clade* c) override;
+};
+
+class gamma_model_reconstruction : public reconstruction {
+    const std::vector<double> _lambda_multipliers;
+    void write_nexus_extensions(std::ostream& ost) override;
+    void print_additional_data(const cladevector& order, familyvector& gene_families, const std::string& output_prefix) override;
+    std::string get_reconstructed_state(const gene_family& gf, const clade* node) override;
+    int get_difference_from_parent(const gene_family* gf, const clade* c) override;
+    int get_node_count(const gene_family& gf, const clade* c) override;
+public:
+    explicit gamma_model_reconstruction(const std::vector<double>& lambda_multipliers) : _lambda_multipliers(lambda_multipliers) {}
+    void print_category_likelihoods(std::ostream& ost, const cladevector& order, familyvector& gene_families);
+    int reconstructed_size(const gene_family& family, const clade* clade) const override;
+    struct gamma_reconstruction {
+        std::vector<std::map<const clade*, int>> category_reconstruction;
+        std::map<const clade*, double> reconstruction;
+        std::vector<double> _category_likelihoods;
+    };
+    std::map<std::string, gamma_reconstruction> _reconstructions;
+};
+// get_weighted_averages, gamma_core.cpp:283-299
+std::map<const clade*, double> get_weighted_averages(const std::vector<std::map<const clade*, int>>& m, const std::vector<double>& probabilities);
+// execute.cpp:163-176: Viterbi branch probabilities for the families with pvalue < test_pvalue
+branch_probabilities compute_branch_probabilities(hip_model_base& mdl, const reconstruction& rec, const std::vector<gene_family>& families,
+                                                  const std::vector<double>& pvalues, double test_pvalue, const cladevector& order);
 
 // ---------------------------------------------------------------- scorers (src/optimizer_scorer.{h,cpp})
 extern std::mt19937 randomizer_engine;

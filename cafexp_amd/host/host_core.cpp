@@ -78,6 +78,17 @@ void clade::validate_lambda_tree(const clade* lambda_tree) const {
     if (mine != theirs) throw std::runtime_error("The lambda tree structure does not match that of the tree");
 }
 
+void clade::write_newick(std::ostream& ost, const std::function<std::string(const clade*)>& textwriter) const {   // clade.cpp:166-183
+    if (is_leaf()) { ost << textwriter(this); return; }
+    ost << '(';
+    for (size_t i = 0; i + 1 < _children.size(); ++i) {
+        _children[i]->write_newick(ost, textwriter);
+        ost << ',';
+    }
+    _children.back()->write_newick(ost, textwriter);
+    ost << ')' << textwriter(this);
+}
+
 void clade::apply_prefix_order(const std::function<void(const clade*)>& f) const {
     std::vector<const clade*> todo{this};
     while (!todo.empty()) {

@@ -179,7 +179,94 @@ static void test_pvalue() {                                   // test.cpp:1175-1
     CHECK(pvalue(1.0, cd) == 0.9);                            // beyond the last entry: index size-1, not size
 }
 
+// report writers of the reconstruction classes: the reference's own expectations
+static void test_reconstruction_reports() {
+    std::unique_ptr<clade> p_tree(parse_newick("((A:1,B:3):7,(C:11,D:17):23);"));           // TEST_GROUP(Reconstruction), test.cpp:865
+    gene_family fam;
+    fam.set_id("Family5");
+    fam.set_species_size("A", 11); fam.set_species_size("B", 2); fam.set_species_size("C", 5); fam.set_species_size("D", 6);
+    cladevector order;
+    for (const char* nm : {"A", "B", "C", "D", "AB", "CD", "ABCD"}) order.push_back(p_tree->find_descendant(nm));
+    const std::vector<gene_family> fams{fam};
+    {   // test.cpp:912 star for significant values, root never significant
+        base_model_reconstruction bmr;
+        auto& values = bmr._reconstructions["Family5"];
+        values[p_tree.get()] = 7; values[p_tree->find_descendant("AB")] = 8; values[p_tree->find_descendant("CD")] = 6;
+        branch_probabilities bp;
+        p_tree->apply_reverse_level_order([&](const clade* c) { bp.set(fam, c, branch_probabilities::branch_probability(.5)); });
+        bp.set(fam, p_tree->find_descendant("AB"), 0.02);
+        bp.set(fam, p_tree.get(), branch_probabilities::invalid());
+        std::ostringstream sig, insig, plain;
+        bmr.print_reconstructed_states(sig, order, fams, p_tree.get(), 0.05, bp);
+        CHECK(sig.str().find("  TREE Family5 = ((A<0>_11:1,B<1>_2:3)<4>*_8:7,(C<2>_5:11,D<3>_6:17)<5>_6:23)<6>_7;") != std::string::npos);
+        bmr.print_reconstructed_states(insig, order, fams, p_tree.get(), 0.01, bp);
+        CHECK(insig.str().find("  TREE Family5 = ((A<0>_11:1,B<1>_2:3)<4>_8:7,(C<2>_5:11,D<3>_6:17)<5>_6:23)<6>_7;") != std::string::npos);
+        branch_probabilities none;                                                       // test.cpp:993
+        bmr.print_reconstructed_states(plain, order, fams, p_tree.get(), 0.05, none);
+        CHECK(plain.str().find("#nexus\nBEGIN TREES;\n  TREE Family5 = ((A<0>_11:1,B<1>_2:3)<4>_8:7,(C<2>_5:11,D<3>_6:17)<5>_6:23)<6>_7;\n\nEND;\n") == 0);
+        std::ostringstream fr, fr2, empty;                                               // test.cpp:2032-2083
+        bmr.print_increases_decreases_by_family(fr, order, fams, {0.03}, 0.01);
+        CHECK(fr.str() == "#FamilyID\tpvalue\tSignificant at 0.01\nFamily5\t0.03\tn\n");
+        bmr.print_increases_decreases_by_family(fr2, order, fams, {0.07}, 0.00001);
+        CHECK(fr2.str().find("#FamilyID\tpvalue\tSignificant at 1e-05\n") == 0);
+        bmr.print_increases_decreases_by_family(empty, order, {}, {}, 0.05);
+        CHECK(empty.str() == "No increases or decreases recorded\n");
+        std::ostringstream cl;                                                           // test.cpp:2146: increases / decreases per clade
+        bmr.print_increases_decreases_by_clade(cl, order, fams);
+        CHECK(cl.str().find("#Taxon_ID\tIncrease\tDecrease\n") == 0 && cl.str().find("A<0>\t1\t0\n") != std::string::npos &&
+              cl.str().find("B<1>\t0\t1\n") != std::string::npos && cl.str().find("<4>\t1\t0\n") != std::string::npos);
+        CHECK(bmr.reconstructed_size(fam, p_tree->find_descendant("AB")) == 8 && bmr.reconstructed_size(fam, p_tree->find_descendant("A")) == 11);
+    }
+    {   // gamma: test.cpp:937, :957, :967, :1079
+        gamma_model_reconstruction gmr(std::vector<double>({0.13, 1.4}));
+        auto& rec = gmr._reconstructions["Family5"];
+        rec.reconstruction[p_tree.get()] = 7; rec.reconstruction[p_tree->find_descendant("AB")] = 8; rec.reconstruction[p_tree->find_descendant("CD")] = 6;
+        branch_probabilities none;
+        std::ostringstream ost;
+        gmr.print_reconstructed_states(ost, order, fams, p_tree.get(), 0.05, none);
+        CHECK(ost.str().find("  TREE Family5 = ((A<0>_11:1,B<1>_2:3)<4>_8:7,(C<2>_5:11,D<3>_6:17)<5>_6:23)<6>_7;") != std::string::npos);
+        CHECK(ost.str().find("\nBEGIN LAMBDA_MULTIPLIERS;\n  0.13;\n  1.4;\nEND;\n\n") != std::string::npos);
+        gamma_model_reconstruction g4(std::vector<double>({0.3, 0.9, 1.4, 2.0}));
+        g4._reconstructions["Family5"]._category_likelihoods = {0.01, 0.03, 0.09, 0.07};
+        std::ostringstream cl;
+        g4.print_category_likelihoods(cl, order, fams);
+        CHECK(cl.str() == "Family ID\t0.3\t0.9\t1.4\t2\t\nFamily5\t0.01\t0.03\t0.09\t0.07\t\n");
+        gamma_model_reconstruction g5(std::vector<double>({.5}));
+        p_tree->apply_prefix_order([&](const clade* c) { g5._reconstructions["Family5"].reconstruction[c] = 5; });
+        std::ostringstream nc;
+        g5.print_node_counts(nc, order, fams, p_tree.get());
+        CHECK(nc.str() == "FamilyID\tA<0>\tB<1>\tC<2>\tD<3>\t<4>\t<5>\t<6>\nFamily5\t11\t2\t5\t6\t5\t5\t5\n");
+        std::ostringstream ch;
+        g5.print_node_change(ch, order, fams, p_tree.get());
+        CHECK(ch.str() == "FamilyID\tA<0>\tB<1>\tC<2>\tD<3>\t<4>\t<5>\t<6>\nFamily5\t+6\t-3\t+0\t+1\t+0\t+0\t+0\n");
+    }
+    {   // test.cpp:1061 weighted averages; :1109-1118 names; :1120-1143 branch probability table
+        clade c1, c2;
+        std::map<const clade*, int> rc1{{&c1, 10}, {&c2, 2}}, rc2{{&c1, 20}, {&c2, 8}};
+        auto avg = get_weighted_averages({rc1, rc2}, {.25, .75});
+        CLOSE(avg[&c1], 17.5, 1e-12);
+        CLOSE(avg[&c2], 6.5, 1e-12);
+        CHECK(clade_index_or_name(p_tree.get(), {p_tree.get()}) == "<0>");
+        auto a = p_tree->find_descendant("A");
+        CHECK(clade_index_or_name(a, {p_tree.get(), a}) == "A<1>");
+        branch_probabilities probs;
+        for (auto c : order) probs.set(fam, c, 0.05);
+        probs.set(fam, p_tree->find_descendant("B"), branch_probabilities::invalid());
+        probs.set(fam, p_tree.get(), branch_probabilities::invalid());
+        std::ostringstream ost, skip;
+        print_branch_probabilities(ost, order, fams, probs);
+        CHECK(ost.str() == "#FamilyID\tA<0>\tB<1>\tC<2>\tD<3>\t<4>\t<5>\t<6>\t\nFamily5\t0.05\tN/A\t0.05\t0.05\t0.05\t0.05\tN/A\n");
+        branch_probabilities nothing;
+        print_branch_probabilities(skip, order, fams, nothing);
+        CHECK(skip.str().find("Family5") == std::string::npos);
+        bool threw = false;
+        try { branch_probabilities::branch_probability bad(1.5); (void)bad; } catch (std::runtime_error&) { threw = true; }
+        CHECK(threw);
+    }
+}
+
 int main() {
+    test_reconstruction_reports();
     test_pvalue();
     test_newick();
     test_families_and_sizes();

@@ -18,7 +18,8 @@ static void usage() {
     std::fprintf(stderr,
         "usage: cafexp_hip -t TREE -i FAMILIES [-l LAMBDA | -m L1,L2,.. -y LAMBDA_TREE | -y LAMBDA_TREE] [-k K] [-a ALPHA]\n"
         "                  [-e [ERRMODEL]] [-p [POISSON_LAMBDA]] [-f ROOTDIST] [-z] [-s SEED] [-I MAXITER] [-d DEVICE] [--reps N] [--family-out FILE] [-o OUTDIR] [--limit N]\n"
-        "                  [--pvalues NSIM [--pvalues-out FILE] [--pvalues-cond FILE:K]] [--sizes M,R]\n");
+        "                  [--pvalues NSIM [--pvalues-out FILE] [--pvalues-cond FILE:K]] [--sizes M,R]\n"
+        "                  [--reconstruct [-P PVALUE]]   (with -o: the reports of reconstruction::write_results)\n");
 }
 
 static std::string slurp_first_line(const std::string& path) {
@@ -39,6 +40,8 @@ int main(int argc, char** argv) {
     std::string tree_path, fam_path, lambda_tree_path, multi, err_path, rootdist_path, family_out, out_dir;
     std::string pvalues_out, pvalues_cond;
     int pvalue_sims = 0, force_m = -1, force_r = -1;
+    bool do_reconstruct = false;
+    double test_pvalue = 0.05;                                   // input_parameters::pvalue default (io.h)
     long limit = -1;
     double fixed_lambda = 0, fixed_alpha = -1, poisson = 0;
     int k = 1, device = 0, max_iter = 300, reps = 1;
@@ -72,6 +75,8 @@ int main(int argc, char** argv) {
             const size_t comma = v.find(',');
             force_m = std::stoi(v.substr(0, comma)); force_r = std::stoi(v.substr(comma + 1));
         }
+        else if (a == "--reconstruct") do_reconstruct = true;
+        else if (a == "-P") test_pvalue = std::stod(next());
         else if (a == "--pvalues") pvalue_sims = std::stoi(next());
         else if (a == "--pvalues-out") pvalues_out = next();
         else if (a == "--pvalues-cond") pvalues_cond = next();
@@ -197,6 +202,20 @@ int main(int argc, char** argv) {
                 }
             }
         }
+        // reconstruct_ancestral_states, Viterbi branch probabilities of the significant families, reports (execute.cpp:163-180)
+        double reconstruct_s = 0;
+        size_t n_with_probs = 0;
+        if (do_reconstruct) {
+            if (pvalues.empty()) pvalues.assign(d.gene_families.size(), 1.0);
+            auto t0 = std::chrono::steady_clock::now();
+            std::unique_ptr<reconstruction> rec(mdl->reconstruct_ancestral_states(d.gene_families, d.p_prior.get()));
+            cladevector order;
+            d.p_tree->apply_reverse_level_order([&order](const clade* c) { order.push_back(c); });
+            branch_probabilities probs = compute_branch_probabilities(*mdl, *rec, d.gene_families, pvalues, test_pvalue, order);
+            reconstruct_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            for (const auto& gf : d.gene_families) n_with_probs += probs.contains(gf);
+            if (!out_dir.empty()) rec->write_results(mdl->name(), out_dir, d.p_tree.get(), d.gene_families, pvalues, test_pvalue, probs);
+        }
         std::printf("{\"model\": \"%s\", ", mdl->name().c_str());
         print_num("neg_lnl", score);
         std::printf("\"n_families\": %zu, \"max_family_size\": %d, \"max_root_family_size\": %d, \"seconds_per_call\": %.6f, ",
@@ -223,6 +242,8 @@ int main(int argc, char** argv) {
             for (double p : pvalues) if (p < 0.05) ++sig;
             std::printf(", \"pvalues\": {\"simulations\": %d, \"seconds\": %.3f, \"significant_at_0.05\": %zu}", pvalue_sims, pvalue_s, sig);
         }
+        if (do_reconstruct)
+            std::printf(", \"reconstruct\": {\"seconds\": %.3f, \"families_with_branch_probabilities\": %zu}", reconstruct_s, n_with_probs);
         std::printf("}\n");
     } catch (const std::exception& e) {
         std::fprintf(stderr, "cafexp_hip: %s\n", e.what());

@@ -96,6 +96,37 @@ def test_oracle_branch_probabilities_match_reference(gr, name):
     _check_bp(got, _golden_bp(e, perm, pb.n_nodes), 1e-11)
 
 
+def _tiny(newick, counts, M, R):
+    from cafexp_amd import problem as P
+    tree = P.parse_newick(newick)
+    species = sorted(counts)
+    pb = P.build_problem(tree, species, ["fam"], np.array([[counts[s] for s in species]], dtype=np.int32), root_filter=False)
+    pb.max_family_size, pb.max_root_family_size = M, R
+    return pb
+
+
+def test_oracle_reconstruct_gene_family_known_answer():
+    """test.cpp:1040: (A:1,B:3):7, A=3 B=6, lambda 0.005, M=10, R=8, root distribution {1,2,3,4,5,4,3,2,1} -> AB = 4."""
+    pb = _tiny("(A:1,B:3):7;", {"A": 3, "B": 6}, 10, 8)
+    rd = np.array([1, 2, 3, 4, 5, 4, 3, 2, 1], dtype=np.float32)
+    got = O.reconstruct(pb, [0.005], rd / np.float32(rd.sum()))[0][0]
+    assert got[pb.node_names.index("AB")] == 4
+
+
+def test_oracle_viterbi_sum_known_answers():
+    """test.cpp:1145-1173: ((A:1,B:3):7,(C:11,D:17):23), A=11, AB=10, lambda 0.05, M=24 -> 0.2182032 for branch A; invalid
+    when parent and child sizes are equal, and at the root."""
+    pb = _tiny("((A:1,B:3):7,(C:11,D:17):23);", {"A": 11, "B": 2, "C": 5, "D": 6}, 24, 24)
+    sizes = np.zeros((1, pb.n_nodes), dtype=np.int32)
+    for name, v in {"A": 11, "B": 2, "C": 5, "D": 6, "AB": 10, "CD": 6, "ABCD": 7}.items():
+        sizes[0, pb.node_names.index(name)] = v
+    bp = O.branch_probabilities(pb, [0.05], sizes)[0]
+    assert abs(bp[pb.node_names.index("A")] - 0.2182032) < 1e-6
+    assert np.isnan(bp[pb.node_names.index("ABCD")]) and np.isnan(bp[pb.node_names.index("D")])      # root; CD == D == 6
+    sizes[0, pb.node_names.index("AB")] = 11
+    assert np.isnan(O.branch_probabilities(pb, [0.05], sizes)[0][pb.node_names.index("A")])
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 def _near_tie_only(pb, pr, rp, got, want, mult):
     """Every family whose reconstruction differs from the reference's must be a rounding-level tie: both joint
@@ -179,3 +210,52 @@ def test_reconstruct_argument_errors(gr):
         ctx.reconstruct(np.array([-1.0]), rp)
     with pytest.raises(capi.CafeError):
         ctx.branch_probabilities(pr.lambdas, np.full((pb.n_families, pb.n_nodes), pb.max_family_size + 1))
+
+
+# ------------------------------------------------------------------------------------------------ driver + reports
+def _run_driver(tmp_path, e, *extra):
+    import subprocess
+    exe = os.path.join(ROOT, "cafexp_amd", "host", "cafexp_hip")
+    assert os.path.exists(exe), "cafexp_hip missing: run __graft_entry__.build()"
+    data = os.path.join(ROOT, "tests", "golden", "data")
+    a = e["args"]
+    cmd = [exe, "-t", os.path.join(data, a["tree"]), "-i", os.path.join(data, a["families"]), "-l", repr(float(a["lambda"])), "--limit", a["limit"],
+           "-s", a["seed"], "--pvalues", a["nsim"], "--reconstruct", "-o", str(tmp_path)]
+    if a.get("model") == "gamma":
+        cmd += ["-k", a["k"], "-a", a["alpha"]]
+    out = subprocess.run([str(x) for x in cmd] + list(extra), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,model", [("mammals_base", "Base"), ("mammals_gamma_k3", "Gamma")])
+def test_driver_reports_match_compiled_reference(gr, tmp_path, name, model):
+    """The whole tail of estimator::execute through cafexp_hip: p-values at the reference's seed, reconstruction,
+    Viterbi branch probabilities of the significant families and every report of reconstruction::write_results,
+    compared as text with what the compiled reference writes for the same inputs."""
+    e = gr[name]
+    d = _run_driver(tmp_path, e)
+    assert abs(d["neg_lnl"] - e["neg_lnl"]) / e["neg_lnl"] < 1e-10
+    read = lambda f: open(os.path.join(str(tmp_path), f)).read()
+    assert read(model + "_family_results.txt") == e["family_results_txt"]            # p-values: same draws as the reference
+    assert read(model + "_count.tab") == e["count_tab"]
+    assert read(model + "_change.tab") == e["change_tab"]
+    assert read(model + "_asr.tre") == e["asr_tre"]
+    # the reference lists clades in the order of their heap addresses: same lines, another order
+    assert sorted(read(model + "_clade_results.txt").splitlines()) == sorted(e["clade_results_txt"].splitlines())
+    got, want = read(model + "_branch_probabilities.tab").splitlines(), e["branch_probabilities_tab"].splitlines()
+    assert len(got) == len(want) and got[0] == want[0]
+    for g, w in zip(got[1:], want[1:]):                                               # 6 significant digits in the file
+        gt, wt = g.split("\t"), w.split("\t")
+        assert gt[0] == wt[0] and len(gt) == len(wt)
+        for x, y in zip(gt[1:], wt[1:]):
+            assert (x == y) or (x != "N/A" and y != "N/A" and abs(float(x) - float(y)) <= 2e-6 * abs(float(y)))
+    if model == "Gamma":
+        got, want = read("Gamma_category_likelihoods.txt").splitlines(), e["category_likelihoods_txt"].splitlines()
+        assert got[0] == want[0] and len(got) == len(want)
+        for g, w in zip(got[1:], want[1:]):
+            gt, wt = g.split("\t"), w.split("\t")
+            assert gt[0] == wt[0]
+            for x, y in zip(gt[1:], wt[1:]):
+                assert x == y or abs(float(x) - float(y)) <= 2e-6 * abs(float(y))
