@@ -65,11 +65,17 @@ __device__ inline double vmax(double a, double b) {
 // (the k-major matrix is zero beyond row M, the panel workspace beyond row M is zeroed once).
 template <bool MUL>
 __global__ __launch_bounds__(256) void maxprod_kernel(const double* __restrict__ Pt, int ldp, const double* __restrict__ B,
-                                                      double* __restrict__ dst, int64_t ld, int M) {
+                                                      double* __restrict__ dst, int64_t ld, int M, int kc_rows) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t f = (int64_t)blockIdx.x * 64 + lane;          // ld is a multiple of 128: always in range
-    const int i0 = __builtin_amdgcn_readfirstlane((blockIdx.y * 4 + wave) * kTI);       // Pt columns i0 .. i0+kTI-1 <-> sizes i0+1 ..
+    // XCD-aware order: workgroups b, b+8, ... share an XCD; consecutive ones there take the row groups of ONE
+    // 64-family column tile, so the panel column is fetched into that L2 once and reused by all of them
+    const int n_rg = (M + kRowsPerBlock - 1) / kRowsPerBlock;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int ct = xcd + 8 * (slot / n_rg), rg = slot % n_rg;
+    if ((int64_t)ct * 64 >= ld) return;
+    const int64_t f = (int64_t)ct * 64 + lane;                  // ld is a multiple of 128: always in range
+    const int i0 = __builtin_amdgcn_readfirstlane((rg * 4 + wave) * kTI);       // Pt columns i0 .. i0+kTI-1 <-> sizes i0+1 ..
     if (i0 >= M) return;
     double acc[kTI];
 #pragma unroll
@@ -80,6 +86,9 @@ __global__ __launch_bounds__(256) void maxprod_kernel(const double* __restrict__
     double bn[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) bn[u] = bp[(int64_t)u * ld];
+    double pn[kTI];                                              // the matrix row of the NEXT step, already requested
+#pragma unroll
+    for (int t = 0; t < kTI; ++t) pn[t] = pp[t];
     for (int g = 0; g < groups; ++g) {
         double b[4];
 #pragma unroll
@@ -90,9 +99,15 @@ __global__ __launch_bounds__(256) void maxprod_kernel(const double* __restrict__
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const double* prow = pp + (int64_t)(4 * g + u) * ldp;   // uniform address: s_load
+            double pc[kTI];
 #pragma unroll
-            for (int t = 0; t < kTI; ++t) acc[t] = vmax(acc[t], b[u] * prow[t]);
+            for (int t = 0; t < kTI; ++t) pc[t] = pn[t];
+            const int next_row = min(4 * g + u + 1, kc_rows - 1);       // stay inside this matrix (rows M+1 .. kc_rows-1 are zero)
+            const double* prow = pp + (int64_t)next_row * ldp;          // uniform address: s_load
+#pragma unroll
+            for (int t = 0; t < kTI; ++t) pn[t] = prow[t];
+#pragma unroll
+            for (int t = 0; t < kTI; ++t) acc[t] = vmax(acc[t], b[u] * pc[t]);
         }
     }
 #pragma unroll
@@ -249,9 +264,10 @@ int reconstruct_impl(cafe_ctx* c, const cafe_params* pr, const float* root_prior
                 } else {
                     const double* Pt = c->kpool.base + (int64_t)slot * c->kpool.stride;
                     const double* B = d_B + (int64_t)bidx[v] * pstride;
-                    dim3 grid((unsigned)(ld / 64), (unsigned)((M + kRowsPerBlock - 1) / kRowsPerBlock));
-                    if (mul) hipLaunchKernelGGL(maxprod_kernel<true>, grid, dim3(256), 0, s, Pt, c->kpool.ld, B, dst, ld, M);
-                    else hipLaunchKernelGGL(maxprod_kernel<false>, grid, dim3(256), 0, s, Pt, c->kpool.ld, B, dst, ld, M);
+                    const int n_ct = (int)(ld / 64), n_rg = (M + kRowsPerBlock - 1) / kRowsPerBlock;
+                    dim3 grid((unsigned)(8 * ((n_ct + 7) / 8) * n_rg));
+                    if (mul) hipLaunchKernelGGL(maxprod_kernel<true>, grid, dim3(256), 0, s, Pt, c->kpool.ld, B, dst, ld, M, c->kpool.rows);
+                    else hipLaunchKernelGGL(maxprod_kernel<false>, grid, dim3(256), 0, s, Pt, c->kpool.ld, B, dst, ld, M, c->kpool.rows);
                 }
                 HIP_TRY(c, hipGetLastError());
             }
