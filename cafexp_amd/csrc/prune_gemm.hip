@@ -101,9 +101,6 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
     const int n_k = (a.k_valid + kBK - 1) / kBK;
     const int last_steps = (a.k_valid - (n_k - 1) * kBK + 3) / 4;
     const int kbytes = (int)(a.panel_kstride * 8 > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : a.panel_kstride * 8);
-    constexpr int SS = 34;                                  // epilogue staging row stride (doubles)
-    const int e_row = lane >> 4, e_col = (lane & 15) * 2;   // epilogue: row inside a group of 4, first of two columns
-    const int gcol = wave * 32 + e_col;
 
     // Tile descriptor (all scalar): buffer resources of the A matrix / child panel / parent panel and origins
     struct Tile {
@@ -194,63 +191,55 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
         for (int kt = 0; kt + 1 < n_k; ++kt) ktile(cur, (kt + 1) * kBK, true, 4);
         ktile(nxt, 0, has_next, last_steps);               // the next output tile's first K tile rides along
 
-        // ---- epilogue.  C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg, i.e.
-        // a lane holds single columns.  Each 16-row block of the wave's 16*MI x 32 sub-tile goes through a small
-        // private LDS image (in the stage that was consumed last; the other one holds the prefetched tile) so
-        // that a lane owns two adjacent columns of one row: 16-byte accesses, 256 B contiguous per row.  All
-        // accesses are buffer operations (descriptor + scalar row offset + fixed lane offset); the old panel
-        // values (MUL) and the leaf factor (LEAF) of row block i+1 are loaded before block i is stored.
-        double* stg = lds + ((g - 1) & 1) * STAGE + wave * (16 * SS);
-        const unsigned c_voff = (unsigned)((e_row * ldb + gcol) * 8);
+        // ---- epilogue.  C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg.  A store
+        // instruction of one accumulator register therefore writes 4 rows x 16 columns = four full 128-byte lines.
+        // All accesses are buffer operations: descriptor + SCALAR offset (row block, register row group, column
+        // half) + one fixed per-lane offset -- no address VALU and no LDS round trip; the old panel values (MUL) and
+        // the leaf factors (LEAF) of row block i+1 are loaded before block i is stored.
+        const unsigned c_voff = (unsigned)((l4 * ldb + wave * 32 + l15) * 8);
         const int c_soff0 = ((cur.row0 + a.out_off) * ldb + cur.col0) * 8;
         __amdgpu_buffer_rsrc_t rsL = cur.rsC;
-        unsigned l_voff0 = 0, l_voff1 = 0;
+        unsigned l_voff[2] = {0, 0};
         int l_soff0 = 0;
         if (LEAF) {
-            const int32_t* cnt = a.counts + (int64_t)a.taxon[0] * a.counts_ld + a.f0 + cur.col0 + gcol;
+            const int32_t* cnt = a.counts + (int64_t)a.taxon[0] * a.counts_ld + a.f0 + cur.col0 + wave * 32 + l15;
             rsL = __builtin_amdgcn_make_buffer_rsrc((void*)(a.lpool.base + (int64_t)a.leaf_slot[0][cur.cat] * a.lpool.stride), 0,
                                                     (int)(a.lpool.stride * 8), 0x00020000);
-            l_voff0 = (unsigned)((e_row * ldl + cnt[0]) * 8);
-            l_voff1 = (unsigned)((e_row * ldl + cnt[1]) * 8);
+            l_voff[0] = (unsigned)((l4 * ldl + cnt[0]) * 8);
+            l_voff[1] = (unsigned)((l4 * ldl + cnt[16]) * 8);
             l_soff0 = (cur.row0 + 1) * ldl * 8;             // parent size row0 + 1
         }
         const int rows_here = a.rows - cur.row0;            // valid rows of this tile (>= BM for interior tiles)
-        struct Pre { double2 f[4]; };
+        struct Pre { double f[2][4]; };
         // FULL: the tile has all BM rows (always true when 16*MI divides the row count): no per-row masks
         auto prefetch = [&](int i, Pre& p, auto full) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int step = i * 16 + q * 4;            // uniform
-                double2 f = make_double2(1.0, 1.0);
-                if (decltype(full)::value || step + e_row < rows_here) {
-                    if (LEAF) {
-                        f.x = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsL, l_voff0, l_soff0 + step * ldl * 8, 0));
-                        f.y = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsL, l_voff1, l_soff0 + step * ldl * 8, 0));
+            for (int r = 0; r < 4; ++r) {
+                const int step = i * 16 + r * 4;            // uniform
+                const bool ok = decltype(full)::value || step + l4 < rows_here;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    double f = 1.0;
+                    if (ok) {
+                        if (LEAF) f = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsL, l_voff[j], l_soff0 + step * ldl * 8, 0));
+                        if (MUL) f *= __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(cur.rsC, c_voff, c_soff0 + (step * ldb + j * 16) * 8, 0));
                     }
-                    if (MUL) {
-                        const double2 old = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(cur.rsC, c_voff, c_soff0 + step * ldb * 8, 0));
-                        f.x *= old.x;
-                        f.y *= old.y;
-                    }
+                    p.f[j][r] = f;
                 }
-                p.f[q] = f;
             }
         };
+        typedef int int2_t __attribute__((ext_vector_type(2)));
         auto flush = [&](int i, const Pre& p, auto full) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int r = 0; r < 4; ++r) {
+                const int step = i * 16 + r * 4;
+                if (decltype(full)::value || step + l4 < rows_here) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) stg[(l4 + 4 * r) * SS + j * 16 + l15] = acc[i][j][r];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                double2 v = *reinterpret_cast<const double2*>(&stg[(q * 4 + e_row) * SS + e_col]);
-                const int step = i * 16 + q * 4;
-                if (decltype(full)::value || step + e_row < rows_here) {
-                    if (MUL || LEAF) {
-                        v.x *= p.f[q].x;
-                        v.y *= p.f[q].y;
+                    for (int j = 0; j < 2; ++j) {
+                        double v = acc[i][j][r];
+                        if (MUL || LEAF) v *= p.f[j][r];
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(int2_t, v), cur.rsC, c_voff, c_soff0 + (step * ldb + j * 16) * 8, 0);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(int4_t, v), cur.rsC, c_voff, c_soff0 + step * ldb * 8, 0);
                 }
             }
         };
@@ -286,10 +275,7 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
             }
             *dst = v;
         }
-        // every wave is done with the staging image before the next tile's DMA may overwrite that stage; the
-        // stores need no wait here (they drain during the next main loop)
-        __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0) only
-        __builtin_amdgcn_s_barrier();
+        // the stores need no wait here (they drain during the next main loop)
         cur = nxt;
     }
     if (a.stamps && tid == 0) {             // diagnostic build only: per-block placement + lifetime (100 MHz ticks)
