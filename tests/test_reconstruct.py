@@ -202,6 +202,58 @@ def test_reconstruction_chunked_and_duplicated_families(gr):
 
 
 @pytest.mark.gpu
+def test_polytomies_and_extinct_families():
+    """Multifurcating nodes (a leaf child of the root, a 3-way interior node) and all-zero / single-taxon families:
+    reconstruction, Viterbi sums and root maxima against the oracle (the reference walks `_descendants` generically)."""
+    from cafexp_amd import capi, problem as P
+    tree = P.parse_newick("((A:3,B:5,C:2):4,(D:6,E:1):2,F:9);")
+    species = ["A", "B", "C", "D", "E", "F"]
+    rng = np.random.default_rng(5)
+    counts = rng.integers(0, 12, size=(300, 6)).astype(np.int32)
+    counts[0] = 0
+    counts[1] = [0, 0, 0, 0, 0, 7]
+    counts[2] = [9, 0, 0, 0, 0, 0]
+    pb = P.build_problem(tree, species, ["f%d" % i for i in range(300)], counts, root_filter=False)
+    lam = np.array([0.02])
+    jmax = min(pb.max_family_size, pb.max_root_family_size)
+    rp = np.zeros(jmax + 1, dtype=np.float32)
+    rp[:pb.max_root_family_size] = P.prior_uniform(pb.max_root_family_size)[:jmax + 1]
+    ctx = capi.Context(pb)
+    got = ctx.reconstruct(lam, rp)[0]
+    want = O.reconstruct(pb, lam, rp)[0]
+    pr = P.Params(lambdas=lam, prior=P.prior_uniform(pb.max_root_family_size))
+    _near_tie_only(pb, pr, rp, got, want, 1.0)
+    _check_bp(ctx.branch_probabilities(lam, want), O.branch_probabilities(pb, lam, want), 1e-9)
+    assert np.max(np.abs(ctx.root_max(lam) / O.root_max(pb, lam) - 1)) < 1e-11
+
+
+@pytest.mark.gpu
+def test_bench_shape_sample_against_oracle():
+    """The bench's 100-taxon / M = 720 shape (matrix order 751, 99 interior nodes): reconstruction, root maxima and
+    Viterbi sums of sampled families against the oracle (its O(N^2) matrix build, itself pinned to the O(N^3) one)."""
+    from cafexp_amd import capi, problem as P, synth
+    pb, _ = synth.make_problem(n_families=2048)
+    lam = np.array([0.002])
+    jmax = min(pb.max_family_size, pb.max_root_family_size)
+    rp = np.zeros(jmax + 1, dtype=np.float32)
+    rp[:pb.max_root_family_size] = P.prior_uniform(pb.max_root_family_size)[:jmax + 1]
+    ctx = capi.Context(pb)
+    st = ctx.reconstruct(lam, rp)[0]
+    rm = ctx.root_max(lam)
+    idx = np.array([0, 1, 777, 2047])
+    sub = P.Problem(parent=pb.parent, branch_length=pb.branch_length, lambda_index=pb.lambda_index, leaf_taxon=pb.leaf_taxon,
+                    counts=np.ascontiguousarray(pb.counts[idx]), max_family_size=pb.max_family_size,
+                    max_root_family_size=pb.max_root_family_size, taxa=pb.taxa, family_ids=[pb.family_ids[i] for i in idx],
+                    node_names=pb.node_names)
+    want = O.reconstruct(sub, lam, rp, fast=True)[0]
+    pr = P.Params(lambdas=lam, prior=P.prior_uniform(pb.max_root_family_size))
+    _near_tie_only(sub, pr, rp, st[idx], want, 1.0)
+    assert np.max(np.abs(rm[idx] / O.root_max(sub, lam, fast=True) - 1)) < 1e-10
+    bp = ctx.branch_probabilities(lam, st)
+    _check_bp(bp[idx], O.branch_probabilities(sub, lam, st[idx], fast=True), 1e-9)
+
+
+@pytest.mark.gpu
 def test_reconstruct_argument_errors(gr):
     from cafexp_amd import capi
     pb, pr, rp, perm = _case(gr["synth20"])
