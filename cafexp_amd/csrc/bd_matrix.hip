@@ -32,11 +32,8 @@
 namespace cafe {
 
 template <int E, bool KMAJOR>
-__global__ __launch_bounds__(64) void bd_matrix_build_kernel(MatrixPool pool, const SlotParam* __restrict__ slots, int n_slots) {
+__device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, const SlotParam sp, int slot) {
     const int lane = threadIdx.x;
-    const int slot = blockIdx.x;
-    if (slot >= n_slots) return;
-    const SlotParam sp = slots[slot];
     double* __restrict__ P = pool.base + (int64_t)slot * pool.stride;
     const int ld = pool.ld;
     const int n = pool.n;                             // matrix order N (sizes 0..N-1)
@@ -135,6 +132,23 @@ __global__ __launch_bounds__(64) void bd_matrix_build_kernel(MatrixPool pool, co
     }
 }
 
+template <int E, bool KMAJOR>
+__global__ __launch_bounds__(64) void bd_matrix_build_kernel(MatrixPool pool, const SlotParam* __restrict__ slots, int n_slots) {
+    const int slot = blockIdx.x;
+    if (slot >= n_slots) return;
+    bd_matrix_build_one<E, KMAJOR>(pool, slots[slot], slot);
+}
+
+// both pools of a scorer call in one launch: each matrix is a latency-bound chain of N row steps on one wave, so the
+// row-major and the k-major matrices should be in flight together rather than one launch after the other
+template <int E>
+__global__ __launch_bounds__(64) void bd_matrix_build_both_kernel(MatrixPool pool, MatrixPool kpool, const SlotParam* __restrict__ slots,
+                                                                  const SlotParam* __restrict__ kslots, int n_slots, int n_kslots) {
+    const int b = blockIdx.x;                          // uniform per wave: no divergence
+    if (b < n_kslots) bd_matrix_build_one<E, true>(kpool, kslots[b], b);          // the longer chains first
+    else if (b - n_kslots < n_slots) bd_matrix_build_one<E, false>(pool, slots[b - n_kslots], b - n_kslots);
+}
+
 int bd_matrix_max_order() { return 64 * 32; }
 
 template <bool KMAJOR>
@@ -148,6 +162,37 @@ static hipError_t launch_layout(const MatrixPool& pool, const SlotParam* d_slots
         (void)hipGetLastError();                                                                                  \
         hipLaunchKernelGGL((bd_matrix_build_kernel<EV, KMAJOR>), grid, block, 0, stream, pool, d_slots, n_slots); \
         return hipGetLastError();                                                                                 \
+    }
+    CAFE_BD_CASE(2)
+    CAFE_BD_CASE(4)
+    CAFE_BD_CASE(6)
+    CAFE_BD_CASE(8)
+    CAFE_BD_CASE(10)
+    CAFE_BD_CASE(12)
+    CAFE_BD_CASE(14)
+    CAFE_BD_CASE(16)
+    CAFE_BD_CASE(20)
+    CAFE_BD_CASE(24)
+    CAFE_BD_CASE(28)
+    CAFE_BD_CASE(32)
+#undef CAFE_BD_CASE
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_bd_matrix_build_both(const MatrixPool& pool, const MatrixPool& kpool, const SlotParam* d_slots, const SlotParam* d_kslots,
+                                       int n_slots, int n_kslots, hipStream_t stream) {
+    if (n_slots <= 0 || n_kslots <= 0) {               // one layout only: the single-pool launch
+        hipError_t e = launch_bd_matrix_build(pool, d_slots, n_slots, stream);
+        return e != hipSuccess ? e : launch_bd_matrix_build(kpool, d_kslots, n_kslots, stream);
+    }
+    const int cols = pool.n;
+    if (cols > bd_matrix_max_order() || (pool.ld & 1) || (kpool.ld & 1) || pool.n != kpool.n) return hipErrorInvalidValue;
+    dim3 grid(n_slots + n_kslots), block(64);
+#define CAFE_BD_CASE(EV)                                                                                                        \
+    if (cols <= 64 * EV) {                                                                                                      \
+        (void)hipGetLastError();                                                                                                \
+        hipLaunchKernelGGL((bd_matrix_build_both_kernel<EV>), grid, block, 0, stream, pool, kpool, d_slots, d_kslots, n_slots, n_kslots); \
+        return hipGetLastError();                                                                                               \
     }
     CAFE_BD_CASE(2)
     CAFE_BD_CASE(4)

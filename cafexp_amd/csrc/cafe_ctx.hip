@@ -378,8 +378,7 @@ int prepare_matrices(cafe_ctx* c, const double* lambdas, const double* multiplie
     if (n_slots) HIP_TRY(c, hipMemcpyAsync(c->d_slots, h_slots, sizeof(SlotParam) * n_slots, hipMemcpyHostToDevice, s));
     if (n_kslots) HIP_TRY(c, hipMemcpyAsync(c->d_slots + c->max_slots, h_kslots, sizeof(SlotParam) * n_kslots, hipMemcpyHostToDevice, s));
     if (c->profile) HIP_TRY(c, hipEventRecord(c->ev[0], s));
-    HIP_TRY(c, launch_bd_matrix_build(c->pool, c->d_slots, n_slots, s));
-    HIP_TRY(c, launch_bd_matrix_build(c->kpool, c->d_slots + c->max_slots, n_kslots, s));
+    HIP_TRY(c, launch_bd_matrix_build_both(c->pool, c->kpool, c->d_slots, c->d_slots + c->max_slots, n_slots, n_kslots, s));
     if (c->profile) HIP_TRY(c, hipEventRecord(c->ev[1], s));
     return CAFE_OK;
 }

@@ -67,11 +67,13 @@ __global__ __launch_bounds__(256) void leaf_gather_kernel(const GatherArgs a) {
     }
 }
 
-// Fast path for the common shape (one or two leaves, no error model, store mode): a thread owns two
-// adjacent families (16-byte stores, 256 threads = 4 KB contiguous per row) and kFastRows rows; the
-// gathers of all its rows are issued before the first store.
+// Fast path for the common shapes (one or two leaves; no error model or a 3-tap one; store or multiply): a thread
+// owns two adjacent families (16-byte accesses, 256 threads = 4 KB contiguous per row) and kFastRows rows; the
+// gathers of all its rows are issued before the first store.  Error-model taps outside [0, M] get weight 0 and a
+// clamped column instead of a branch: fac = sum_i err[x][i] * P[s][x - half + i] in the reference's tap order
+// (probability.cpp:187-196 builds the leaf vector, matrix_cache.cpp:28 multiplies it).
 constexpr int kFastRows = 8;
-template <int NLEAF>
+template <int NLEAF, int NDEV, bool MUL>
 __global__ __launch_bounds__(256) void leaf_gather_fast_kernel(const GatherArgs a) {
     const int cat = blockIdx.z;
     const int f = (blockIdx.x * 256 + threadIdx.x) * 2;
@@ -79,13 +81,23 @@ __global__ __launch_bounds__(256) void leaf_gather_fast_kernel(const GatherArgs 
     const int r0 = blockIdx.y * kFastRows;
     const unsigned ldp = (unsigned)a.pool.ld;
     double* __restrict__ dst = a.dst + (int64_t)cat * a.panel_kstride + (int64_t)r0 * a.ld + f;
-    unsigned o0[NLEAF], o1[NLEAF];
+    unsigned o0[NLEAF][NDEV], o1[NLEAF][NDEV];
+    double w0[NLEAF][NDEV], w1[NLEAF][NDEV];
     const double* P[NLEAF];
+    constexpr int half = (NDEV - 1) / 2;
 #pragma unroll
     for (int l = 0; l < NLEAF; ++l) {
         const int32_t* cnt = a.counts + (int64_t)a.taxon[l] * a.counts_ld + a.f0 + f;
-        o0[l] = (unsigned)cnt[0];
-        o1[l] = (unsigned)cnt[1];
+        const int x0 = cnt[0], x1 = cnt[1];
+#pragma unroll
+        for (int i = 0; i < NDEV; ++i) {
+            const int c0 = x0 - half + i, c1 = x1 - half + i;
+            const bool ok0 = c0 >= 0 && c0 <= a.max_family_size, ok1 = c1 >= 0 && c1 <= a.max_family_size;
+            o0[l][i] = (unsigned)(ok0 ? c0 : x0);
+            o1[l][i] = (unsigned)(ok1 ? c1 : x1);
+            w0[l][i] = NDEV == 1 ? 1.0 : (ok0 ? a.err[(int64_t)x0 * NDEV + i] : 0.0);
+            w1[l][i] = NDEV == 1 ? 1.0 : (ok1 ? a.err[(int64_t)x1 * NDEV + i] : 0.0);
+        }
         P[l] = a.pool.base + (int64_t)a.slot[l][cat] * a.pool.stride + (int64_t)(r0 + a.row_off) * ldp;
     }
     double2 v[kFastRows];
@@ -97,8 +109,24 @@ __global__ __launch_bounds__(256) void leaf_gather_fast_kernel(const GatherArgs 
 #pragma unroll
             for (int l = 0; l < NLEAF; ++l) {
                 const double* row = P[l] + (unsigned)rr * ldp;
-                x *= row[o0[l]];
-                y *= row[o1[l]];
+                if (NDEV == 1) {
+                    x *= row[o0[l][0]];
+                    y *= row[o1[l][0]];
+                } else {
+                    double fx = 0.0, fy = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NDEV; ++i) {
+                        fx += row[o0[l][i]] * w0[l][i];
+                        fy += row[o1[l][i]] * w1[l][i];
+                    }
+                    x *= fx;
+                    y *= fy;
+                }
+            }
+            if (MUL) {
+                const double2 old = *reinterpret_cast<const double2*>(dst + (int64_t)rr * a.ld);
+                x *= old.x;
+                y *= old.y;
             }
             v[rr] = make_double2(x, y);
         }
@@ -108,12 +136,19 @@ __global__ __launch_bounds__(256) void leaf_gather_fast_kernel(const GatherArgs 
         if (r0 + rr < a.rows_store) *reinterpret_cast<double2*>(dst + (int64_t)rr * a.ld) = v[rr];
 }
 
+template <int NLEAF, int NDEV>
+static void launch_fast(const GatherArgs& a, dim3 grid, hipStream_t stream) {
+    if (a.mode) hipLaunchKernelGGL((leaf_gather_fast_kernel<NLEAF, NDEV, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((leaf_gather_fast_kernel<NLEAF, NDEV, false>), grid, dim3(256), 0, stream, a);
+}
+
 hipError_t launch_leaf_gather(const GatherArgs& a, int n_categories, hipStream_t stream) {
     (void)hipGetLastError();
-    if (a.err == nullptr && a.mode == 0 && a.n_leaf >= 1 && a.n_leaf <= 2) {
-        dim3 grid((a.ld / 2 + 255) / 256, (a.rows_store + kFastRows - 1) / kFastRows, n_categories), block(256);
-        if (a.n_leaf == 1) hipLaunchKernelGGL(leaf_gather_fast_kernel<1>, grid, block, 0, stream, a);
-        else hipLaunchKernelGGL(leaf_gather_fast_kernel<2>, grid, block, 0, stream, a);
+    const int ndev = a.err == nullptr ? 1 : a.n_dev;
+    if ((ndev == 1 || ndev == 3) && a.n_leaf >= 1 && a.n_leaf <= 2) {
+        dim3 grid((a.ld / 2 + 255) / 256, (a.rows_store + kFastRows - 1) / kFastRows, n_categories);
+        if (a.n_leaf == 1) { if (ndev == 1) launch_fast<1, 1>(a, grid, stream); else launch_fast<1, 3>(a, grid, stream); }
+        else { if (ndev == 1) launch_fast<2, 1>(a, grid, stream); else launch_fast<2, 3>(a, grid, stream); }
         return hipGetLastError();
     }
     dim3 grid((a.ld + 255) / 256, (a.rows_store + kGatherRows - 1) / kGatherRows, n_categories), block(256);

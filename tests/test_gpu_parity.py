@@ -330,6 +330,28 @@ def test_config4_shape_properties(capi, oracle):
     assert rel_err(capi.Context(doubled, max_categories=8).score(pr, alpha=2.0), 2 * whole) <= 1e-12
 
 
+def test_config5_shape_properties(capi, oracle):
+    """BASELINE config 5 shape: the 100-taxon tree with a second lambda on one clade (>= 10 taxa), the default error
+    model rows {0,.95,.05} / {.05,.9,.05}, base model; a family subset against the oracle plus shard additivity."""
+    from cafexp_amd import synth
+    pb, _ = synth.make_problem(n_families=1536, lambda_clade_min=10, n_deviations=3)
+    assert pb.n_lambdas == 2 and not pb.single_lambda and pb.matrix_size == 751
+    em = P.error_model_table(P.default_error_model(pb.max_family_size)[:1] + [[0.05, 0.9, 0.05]], pb.max_family_size)
+    pr = P.Params(lambdas=np.array([0.002, 0.004]), prior=P.prior_uniform(pb.max_root_family_size), error_model=em)
+    ctx = capi.Context(pb)
+    whole, res = ctx.score(pr, per_family=True)
+    assert math.isfinite(whole)
+    sel = np.array([0, 3, 700, 1535])
+    sub = dataclasses.replace(pb, counts=pb.counts[sel].copy(), family_ids=[pb.family_ids[i] for i in sel])
+    _, fam = oracle.score_base(sub, pr, fast=True, per_family=True)
+    assert np.abs(res["family_lnl"][sel] / fam - 1).max() <= VEC_TOL
+    parts = 0.0
+    for lo, hi in [P.shard_families(pb.n_families, 2, r) for r in range(2)]:
+        shard = dataclasses.replace(pb, counts=pb.counts[lo:hi].copy(), family_ids=pb.family_ids[lo:hi])
+        parts += capi.Context(shard).score(pr)
+    assert rel_err(parts, whole) <= 1e-12
+
+
 def test_partial_api_on_torch_stream(capi, oracle):
     """cafe_score_partial leaves {sum lnL, rejects} in device memory on the caller's stream (the multi-GPU path)."""
     import torch
