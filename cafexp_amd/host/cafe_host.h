@@ -177,6 +177,8 @@ class poisson_distribution : public root_equilibrium_distribution {
     double _lambda;
 public:
     explicit poisson_distribution(double pl) : _lambda(pl) {}
+    explicit poisson_distribution(const std::vector<gene_family>* p_gene_families);     // fitted: root_equilibrium_distribution.cpp:34-45
+    double poisson_lambda() const { return _lambda; }
     void initialize(const root_distribution* rd) override;
     float compute(size_t val) const override { return val >= _pdf.size() ? 0 : (float)_pdf[val]; }
 };
@@ -388,6 +390,15 @@ public:
     virtual ~optimizer_scorer() {}
     virtual std::vector<double> initial_guesses() = 0;
     virtual double calculate_score(const double* values) = 0;
+};
+// empirical Poisson prior: -lnL of the leaf sizes shifted by one (src/poisson.cpp:38-77)
+class poisson_scorer : public optimizer_scorer {
+    std::vector<int> leaf_family_sizes;
+public:
+    explicit poisson_scorer(const std::vector<gene_family>& gene_families);
+    std::vector<double> initial_guesses() override;
+    double calculate_score(const double* values) override { return lnLPoisson(values); }
+    double lnLPoisson(const double* plambda);
 };
 class inference_optimizer_scorer : public optimizer_scorer {
 protected:

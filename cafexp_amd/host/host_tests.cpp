@@ -265,7 +265,23 @@ static void test_reconstruction_reports() {
     }
 }
 
+static void test_poisson_scorer() {                           // test.cpp:2270-2287 (fixture: A=1, B=2)
+    std::vector<gene_family> fams(1);
+    fams[0].set_id("TestFamily1"); fams[0].set_species_size("A", 1); fams[0].set_species_size("B", 2);
+    double lambda = 0.05;
+    poisson_scorer s1(fams);
+    CLOSE(s1.lnLPoisson(&lambda), 3.095732, 1e-4);
+    fams.resize(2);
+    fams[1].set_id("TestFamily2"); fams[1].set_species_size("A", 3); fams[1].set_species_size("B", 175);
+    poisson_scorer s2(fams);
+    CLOSE(s2.lnLPoisson(&lambda), 9.830344, 1e-4);           // the 175 is incalculable at this rate and skipped
+    fams[1].set_species_size("B", 4);
+    poisson_distribution fitted(&fams);                       // maximum likelihood of a Poisson on sizes-1 = their mean
+    CLOSE(fitted.poisson_lambda(), (0 + 1 + 2 + 3) / 4.0, 1e-3);
+}
+
 int main() {
+    test_poisson_scorer();
     test_reconstruction_reports();
     test_pvalue();
     test_newick();

@@ -123,7 +123,7 @@ int main(int argc, char** argv) {
         }
         if (limit >= 0 && (size_t)limit < d.gene_families.size()) d.gene_families.resize(limit);
         if (use_poisson && poisson > 0) d.p_prior.reset(new poisson_distribution(poisson));
-        else if (use_poisson) throw std::runtime_error("-p without a value (empirical Poisson prior) is not supported by this driver");
+        else if (use_poisson) d.p_prior.reset(new poisson_distribution(&d.gene_families));     // fitted to the leaf sizes (root_equilibrium_distribution.cpp:34)
         else d.p_prior.reset(new uniform_distribution());
 
         // build_models (core.cpp:16-50): gamma iff fixed_alpha > 0 or K > 1; default error model for -e without a file

@@ -88,4 +88,35 @@ void gamma_lambda_optimizer::finalize(double* results) {
     _gamma_optimizer.finalize(results + _p_lambda->count());
 }
 
+// ---------------------------------------------------------------- empirical Poisson prior (src/poisson.cpp)
+static double poisspdf(int x, double lambda) { return std::exp(x * std::log(lambda) - std::lgamma(x + 1) - lambda); }
+
+poisson_scorer::poisson_scorer(const std::vector<gene_family>& gene_families) {
+    for (auto& fam : gene_families)
+        for (const auto& species : fam.get_species())
+            if (fam.get_species_size(species) > 0) leaf_family_sizes.push_back(fam.get_species_size(species) - 1);
+}
+
+std::vector<double> poisson_scorer::initial_guesses() {
+    std::uniform_real_distribution<double> distribution(0.0, 1.0);
+    return std::vector<double>{distribution(randomizer_engine)};
+}
+
+double poisson_scorer::lnLPoisson(const double* plambda) {
+    const double lambda = plambda[0];
+    double score = 0.0;
+    for (int sz : leaf_family_sizes) {
+        const double ll = poisspdf(sz, lambda);
+        if (std::isnan(ll) || std::isinf(ll) || ll == 0) continue;      // incalculable sizes are skipped (poisson.cpp:69)
+        score += std::log(ll);
+    }
+    return -score;
+}
+
+poisson_distribution::poisson_distribution(const std::vector<gene_family>* p_gene_families) {
+    poisson_scorer scorer(*p_gene_families);
+    optimizer opt(&scorer);
+    _lambda = opt.optimize().values[0];
+}
+
 }  // namespace cafe
