@@ -99,6 +99,7 @@ public:
     std::vector<double> get_epsilons() const;
     void replace_epsilons(const std::map<double, double>& replacements);
     void update_single_epsilon(double eps);
+    const std::vector<int>& deviations() const { return _deviations; }
 private:
     size_t _max_family_size = 0;
     std::vector<int> _deviations;
@@ -472,6 +473,7 @@ struct user_data {
 };
 void read_gene_families(std::istream& in, const clade* tree, std::vector<gene_family>& out);    // io.cpp:134
 void read_error_model_file(std::istream& in, error_model* em);                                  // io.cpp:226
+void write_error_model_file(std::ostream& ost, const error_model& em);                          // io.cpp:275
 void read_rootdist(std::istream& in, std::map<int, int>& out);                                  // user_data.cpp:103
 void compute_max_sizes(const std::vector<gene_family>& fams, int& max_family_size, int& max_root_family_size);   // user_data.cpp:37-46
 

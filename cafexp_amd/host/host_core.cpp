@@ -478,6 +478,22 @@ void compute_max_sizes(const std::vector<gene_family>& fams, int& max_family_siz
     max_family_size = mx + std::max(50, mx / 5);                                       // user_data.cpp:46
 }
 
+void write_error_model_file(std::ostream& ost, const error_model& errormodel) {        // io.cpp:275-295
+    ost << "maxcnt: " << errormodel.get_max_family_size() - 1 << "\n";
+    ost << "cntdiff:";
+    for (int j : errormodel.deviations()) ost << " " << j;
+    ost << "\n";
+    std::vector<double> last_probs;
+    for (size_t j = 0; j < errormodel.get_max_family_size(); j++) {
+        auto probs = errormodel.get_probs(j);
+        if (probs == last_probs) continue;
+        last_probs = probs;
+        ost << j;
+        for (auto p : probs) ost << " " << p;
+        ost << std::endl;
+    }
+}
+
 // ---------------------------------------------------------------- p-values
 double pvalue(double v, const std::vector<double>& conddist) {                  // probability.cpp:379-389
     int idx = (int)conddist.size() - 1;

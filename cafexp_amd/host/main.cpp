@@ -174,6 +174,15 @@ int main(int argc, char** argv) {
             mdl->write_vital_statistics(rf, score);
             std::ofstream lf(out_dir + "/" + mdl->name() + "_family_likelihoods.txt");
             mdl->write_family_likelihoods(lf);
+            if (use_err) {                                       // write_error_model_if_specified (execute.cpp:24-40)
+                std::ofstream ef(out_dir + "/" + mdl->name() + "_error_model.txt");
+                if (em) write_error_model_file(ef, *em);
+                else {                                           // model::write_error_model's stand-in (core.cpp:118-127)
+                    error_model none;
+                    none.set_probabilities(d.max_family_size, {0, 1, 0});
+                    write_error_model_file(ef, none);
+                }
+            }
         }
         // compute_pvalues with the model's plain lambda (execute.cpp:153-161); 1000 simulations in the reference
         std::vector<double> pvalues;

@@ -7,6 +7,9 @@
  *          gamma_model::infer_family_likelihoods src/gamma_core.cpp:169
  * i.e. matrix_cache::precalculate_matrices (src/matrix_cache.cpp:121), inference_prune
  * (src/core.cpp:133) for every family (and gamma category) and the per-family root reduction.
+ * and, for what the reference runs once after the search (estimator::execute, src/execute.cpp:147-180):
+ * the prunes of compute_pvalues (cafe_root_max), Pupko's reconstruction (cafe_reconstruct) and the Viterbi branch
+ * probabilities (cafe_branch_probabilities).
  * Everything behind this header is hand-written HIP for gfx950; there is no CPU fallback:
  * every entry point fails (non-zero code / NULL + message) when no HIP device is usable.
  *

@@ -23,6 +23,8 @@
 //             [nsim= seed= pvalue=0.05 files=1]   the tail of estimator::execute (execute.cpp:147-180): infer once,
 //             [compute_pvalues,] reconstruct_ancestral_states, compute_viterbi_sum for every family and node;
 //             files=1 adds the text of every report reconstruction::write_results writes
+//   cafexp    <the reference program's own command line>   runs cafexp() (src/cafexp.cpp:175) unchanged, e.g.
+//             ref_harness cafexp -t tree -i families -k 3 -o /tmp/out ; prints {"rc": .., "seconds": ..}
 //   pvalues   tree= families= lambda=|lambdas= lambda_tree= [nsim=1000] [seed=10] [ncond=0] [limit=] [m= r=]
 //             compute_pvalues at a fixed seed of the global engine; ncond > 0 also prints the sorted conditional
 //             distributions get_random_probabilities returns for root sizes 0..ncond-1 (same seed, same order)
@@ -56,6 +58,7 @@
 #include "src/gene_family_reconstructor.h"
 
 std::mt19937 randomizer_engine(10);   // main.cpp:3 / test.cpp:35 define this global
+int cafexp(int argc, char* const argv[]);   // src/cafexp.cpp:175
 void init_lgamma_cache();             // probability.cpp:66
 
 typedef std::map<std::string, std::string> kv_t;
@@ -419,8 +422,15 @@ static int job_time_matrices(const kv_t& kv) {
 
 int main(int argc, char** argv) {
     if (argc < 2) { fprintf(stderr, "usage: ref_harness <job> key=value...\n"); return 2; }
-    init_lgamma_cache();
     std::string job(argv[1]);
+    if (job == "cafexp") {                      // the whole program, its own argument parser (argv[0] = "cafexp")
+        double t0 = now();
+        int rc = cafexp(argc - 1, argv + 1);
+        fflush(stdout);
+        printf("\n{\"rc\": %d, \"seconds\": %.3f, \"threads\": %d}\n", rc, now() - t0, omp_get_max_threads());
+        return rc;
+    }
+    init_lgamma_cache();
     kv_t kv = parse_args(argc, argv, 2);
     try {
         // the reference prints progress to cout (e.g. "Found root!", "Score (-lnL)") unless built -DSILENT

@@ -99,7 +99,44 @@ def make_reconstruct():
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def make_runs():
+    """tests/golden/ref_runs.json: the reference PROGRAM itself (cafexp(), src/cafexp.cpp:175, through `ref_harness cafexp`)
+    searching lambda+alpha, two lambdas, and lambda+epsilon on the first 1500 rows of its example family table."""
+    import shutil
+    import tempfile
+    data = lambda n: os.path.join(D, n)
+    with open(data("mammal_gene_families.txt")) as f:
+        lines = f.readlines()[:1501]
+    with open(data("mammals_1500.txt"), "w") as f:
+        f.writelines(lines)
+    runs = {}
+    for name, model, args in [("g3", "Gamma", ["-k", "3"]), ("ml", "Base", ["-y", "chimphuman_separate_lambda.txt"]), ("em", "Base", ["-e"])]:
+        print("ref program:", name, flush=True)
+        out_dir = tempfile.mkdtemp(prefix="ref_run_")
+        argv = [O.REF_HARNESS, "cafexp", "-t", data("mammals_tree.txt"), "-i", data("mammals_1500.txt")]
+        argv += [data(a) if a.endswith(".txt") else a for a in args] + ["-o", out_dir]
+        import subprocess
+        log = subprocess.run(argv, check=True, capture_output=True, text=True).stdout
+        e = {"args": args, "model": model, "results_txt": open(os.path.join(out_dir, model + "_results.txt")).read(),
+             "harness": json.loads(log.strip().splitlines()[-1])}
+        if name == "em":
+            e["error_model_txt"] = open(os.path.join(out_dir, "Base_error_model.txt")).read()
+        runs[name] = e
+        shutil.rmtree(out_dir)
+    out = {"generator": "tests/golden/make_golden.py runs  (oracle/_ref/ref_harness cafexp -t mammals_tree.txt -i mammals_1500.txt <args> -o DIR: "
+                        "the reference program itself, its own random initial guesses; mammals_1500.txt = header + first 1500 rows of the "
+                        "reference's example table)", "runs": runs}
+    path = os.path.join(HERE, "ref_runs.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", path)
+
+
 def main():
+    if sys.argv[1:] == ["runs"]:
+        if not O.have_ref():
+            raise SystemExit("oracle/_ref/ref_harness missing: run `make -C oracle ref` in the build container")
+        return make_runs()
     if sys.argv[1:] == ["reconstruct"]:
         if not O.have_ref():
             raise SystemExit("oracle/_ref/ref_harness missing: run `make -C oracle ref` in the build container")
