@@ -61,7 +61,7 @@ struct GemmArgs {
     int32_t n_row_tiles;
     int32_t n_col_tiles;
     int32_t n_categories;           // filled by launch_prune_gemm
-    unsigned long long* stamps;     // diagnostic: 6 words per block (placement + timeline), nullptr in production
+    unsigned long long* stamps;     // diagnostic: 6 words per workgroup (placement, epilogue ticks, tiles, lifetime), nullptr in production
     // leaf siblings folded into the epilogue (K3's work for a parent with leaf and interior children)
     MatrixPool lpool;               // row-major pool
     int32_t n_leaf;

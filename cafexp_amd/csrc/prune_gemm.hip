@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: LDS-DMA bases (M0) need no VALU
     const int l15 = lane & 15, l4 = lane >> 4;
     const int lda = a.pool.ld, ldb = a.ld, ldl = a.lpool.ld;
-    unsigned long long st0 = 0;
+    unsigned long long st0 = 0, ep_ticks = 0, n_done = 0;
     if (a.stamps) st0 = __builtin_amdgcn_s_memrealtime();
 
     // ---- persistent tile loop.  The grid is 2 workgroups per CU; a workgroup walks a fixed list of output
@@ -143,17 +143,19 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
     };
 
     if (local >= n_tiles) return;
-    Tile cur = decode(local);
+    {
+        const Tile first = decode(local);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) stage_quarter(cur, 0, 0, q);
+        for (int q = 0; q < 4; ++q) stage_quarter(first, 0, 0, q);
+    }
     int g = 0;                                              // running K-tile count: stage parity
     __syncthreads();                                        // vmcnt(0) + barrier: the first K tile has landed (later
                                                             // ones land behind the barrier that ends each K tile)
 
     for (int t = local; t < n_tiles; t += n_local_blocks) {
         const bool has_next = t + n_local_blocks < n_tiles;
-        Tile nxt = cur;
-        if (has_next) nxt = decode(t + n_local_blocks);
+        const Tile cur = decode(t);                         // scalar work, once per output tile; cheaper than carrying it
+        const Tile nxt = decode(has_next ? t + n_local_blocks : t);   // only its A/B descriptors and origins are used (DMA)
 
         double4_t acc[MI][2];                               // zeroed while the first K tile is in flight
 #pragma unroll
@@ -162,34 +164,82 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
             acc[i][1] = double4_t{0.0, 0.0, 0.0, 0.0};
         }
 
-        // One K tile (rows c > M of the k-major matrix are zero, so padded k inside a step adds exact zeros;
-        // whole padded k-steps of the last tile are skipped).  A DMA quarter of the following K tile is issued
-        // ahead of the MFMAs of every step.  (A second fragment register set, prefetching step s+1, measured
-        // worth nothing -- the co-resident workgroup covers the LDS latency -- and costs 22 VGPRs.)
-        auto ktile = [&](const Tile& sx, int sk0, bool do_stage, int n_steps) {
+        // ---- main loop.  Rows c > M of the k-major matrix are zero, so padded k inside a step adds exact zeros; whole
+        // padded k-steps of the last K tile are skipped.  The full K tiles are software-pipelined at the k-step level
+        // with ONE fragment register set: the A fragment of row block i for step s+1 is read right after the two MFMAs
+        // that consume it in step s (MFMAs read their operands at issue), the two B fragments alternate between two
+        // pairs.  A wave alone on its SIMD then keeps the matrix pipe fed (tools/fp64_probe3: 78 TFLOP/s), where a
+        // "read everything, wait, 18 MFMAs" step leaves a bubble of one LDS latency per step (an ablated copy of this
+        // kernel without DMA, barriers and epilogue: 71.8 TFLOP/s).  The barrier that hands over a stage sits in front
+        // of a K tile's last step, after that step's fragments were read, so that the same step can already read the
+        // next tile's first fragments; the DMA quarters of a K tile go out in the four steps before that barrier.
+        double af[MI], bfr[2][2];
+        auto read_b = [&](const double* base, int s4, double (&b)[2]) {
+            b[0] = base[b_off + s4 * 4 * kBStride];
+            b[1] = base[b_off + s4 * 4 * kBStride + 16];
+        };
+        {   // cold start of the output tile: its K tile 0 has landed (prologue / the barrier that ended the previous tile)
+            const double* base = lds + (g & 1) * STAGE;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = base[a_off + i * 16];
+            read_b(base, 0, bfr[0]);
+        }
+        for (int kt = 0; kt + 1 < n_k; ++kt) {
             const int buf = g & 1;
             const double* base = lds + buf * STAGE;
+            const double* nbase = lds + (buf ^ 1) * STAGE;
+            const int k1 = (kt + 1) * kBK;                  // K tile being staged into the other stage
+            const bool next_full = kt + 2 < n_k;            // K tile kt+1 is another pipelined one (not the ragged last)
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
-                if (do_stage) stage_quarter(sx, sk0, buf ^ 1, s4);
-                if (s4 < n_steps) {
-                    double af[MI], bf[2];
+                if (s4 < 3) {
+                    if (s4 == 0 && kt == 0) stage_quarter(cur, k1, buf ^ 1, 0);   // no earlier step to carry it
+                    stage_quarter(cur, k1, buf ^ 1, s4 + 1);
+                } else {
+                    __syncthreads();                        // K tile kt+1 has landed; every wave has read all of K tile kt
+                    if (next_full) stage_quarter(cur, k1 + kBK, buf, 0);
+                    else if (has_next) stage_quarter(nxt, 0, buf, 0);
+                }
+                const bool pre = s4 < 3 || next_full;       // uniform
+                const double* src = s4 < 3 ? base : nbase;
+                const int ns = (s4 + 1) & 3;
+                if (pre) read_b(src, ns, bfr[(s4 + 1) & 1]);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bfr[s4 & 1][0], acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bfr[s4 & 1][1], acc[i][1], 0, 0, 0);
+                    if (pre) af[i] = src[a_off + ns * 4 * SA + i * 16];
+                    __builtin_amdgcn_sched_barrier(0);      // keep "two MFMAs, then the read that reuses their register"
+                }
+            }
+            ++g;
+        }
+        {   // last K tile: last_steps of its four steps hold valid k; plain read -> MFMA steps.  The next output tile's
+            // first K tile rides along (its first quarter went out in front of this tile unless this is the only one).
+            const int buf = g & 1;
+            const double* base = lds + buf * STAGE;
+            if (has_next) {
+                if (n_k == 1) stage_quarter(nxt, 0, buf ^ 1, 0);
+                stage_quarter(nxt, 0, buf ^ 1, 1);
+                stage_quarter(nxt, 0, buf ^ 1, 2);
+                stage_quarter(nxt, 0, buf ^ 1, 3);
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                if (s4 < last_steps) {
 #pragma unroll
                     for (int i = 0; i < MI; ++i) af[i] = base[a_off + s4 * 4 * SA + i * 16];
-                    bf[0] = base[b_off + s4 * 4 * kBStride];
-                    bf[1] = base[b_off + s4 * 4 * kBStride + 16];
+                    read_b(base, s4, bfr[0]);
 #pragma unroll
                     for (int i = 0; i < MI; ++i) {
-                        acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[0], acc[i][0], 0, 0, 0);
-                        acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[1], acc[i][1], 0, 0, 0);
+                        acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bfr[0][0], acc[i][0], 0, 0, 0);
+                        acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bfr[0][1], acc[i][1], 0, 0, 0);
                     }
                 }
             }
-            __syncthreads();                                // the staged tile landed, this one fully read
+            __syncthreads();                                // the next output tile's K tile 0 landed, this one fully read
             ++g;
-        };
-        for (int kt = 0; kt + 1 < n_k; ++kt) ktile(cur, (kt + 1) * kBK, true, 4);
-        ktile(nxt, 0, has_next, last_steps);               // the next output tile's first K tile rides along
+        }
 
         // ---- epilogue.  C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg.  A store
         // instruction of one accumulator register therefore writes 4 rows x 16 columns = four full 128-byte lines.
@@ -254,8 +304,11 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
                 flush(i, pre[i & 1], full);
             }
         };
+        unsigned long long e0 = 0;
+        if (a.stamps) e0 = __builtin_amdgcn_s_memrealtime();
         if (rows_here >= BM) epilogue(std::true_type{});
         else epilogue(std::false_type{});
+        if (a.stamps) { ep_ticks += __builtin_amdgcn_s_memrealtime() - e0; n_done += 1; }
         // parent size 0 only reaches child size 0 (P[0][c] = delta(c,0)): that panel row is the child's row 0,
         // times the leaf sibling's P_leaf[0][x] = delta(x,0)
         if (a.out_off == 1 && cur.row_tile == 0 && tid < kBN / 2) {
@@ -276,13 +329,12 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
             *dst = v;
         }
         // the stores need no wait here (they drain during the next main loop)
-        cur = nxt;
     }
     if (a.stamps && tid == 0) {             // diagnostic build only: per-block placement + lifetime (100 MHz ticks)
         unsigned long long* o = a.stamps + 6 * (size_t)blockIdx.x;
         o[0] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
         o[1] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
-        o[2] = st0; o[3] = st0; o[4] = st0; o[5] = __builtin_amdgcn_s_memrealtime();
+        o[2] = st0; o[3] = ep_ticks; o[4] = n_done; o[5] = __builtin_amdgcn_s_memrealtime();
     }
 #else
     (void)a;
