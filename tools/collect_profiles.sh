@@ -23,3 +23,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES S
 # the per-dispatch traces are large; keep what the summaries need
 find $OUT/prof -name "*kernel_trace.csv" -delete
 tail -1 $OUT/bench_full.json
+echo "[6] reconstruction kernels at the bench shape"
+rm -rf $OUT/prof_recon
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_recon -o run --output-format csv -- python3 $R/tools/reconstruct_scale.py 50000 > $OUT/prof_recon.log 2>&1
+find $OUT/prof_recon -name "*kernel_trace.csv" -delete
+grep "reconstruct:" $OUT/prof_recon.log | tail -1
