@@ -138,20 +138,34 @@ __global__ __launch_bounds__(256) void root_select_kernel(const double* __restri
     state[f] = arg;
 }
 
-// interior node: state = first arg max_j B[j] * P[i][j], i = the parent's state; P[i][j] = Pt[j][i-1], row 0 = e_0
+// interior node: state = first arg max_j B[j] * P[i][j], i = the parent's state; P[i][j] = Pt[j][i-1], row 0 = e_0.
+// 64 families per block; the j range is cut into four consecutive segments scanned by four threads per family and
+// combined in segment order with the same strict comparison, which keeps the reference's "first maximum".
 __global__ __launch_bounds__(256) void backtrack_kernel(const double* __restrict__ Pt, int ldp, const double* __restrict__ B, int64_t ld,
                                                         int M, const int32_t* __restrict__ parent_state, int32_t* __restrict__ state) {
-    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (f >= ld) return;
+    __shared__ double s_best[4][64];
+    __shared__ int s_arg[4][64];
+    const int fl = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int64_t f = (int64_t)blockIdx.x * 64 + fl;          // ld is a multiple of 128: always in range
     const int i = parent_state[f];
+    const int per = (M + 4) / 4;                               // ceil((M + 1) / 4)
+    const int j0 = seg * per, j1 = min(M + 1, j0 + per);
     double best = -1.0;
     int arg = 0;
-    for (int j = 0; j <= M; ++j) {
+    for (int j = j0; j < j1; ++j) {
         const double p = i == 0 ? (j == 0 ? 1.0 : 0.0) : Pt[(int64_t)j * ldp + (i - 1)];
         const double val = B[(int64_t)j * ld + f] * p;
         if (val > best) { best = val; arg = j; }
     }
-    state[f] = arg;
+    s_best[seg][fl] = best;
+    s_arg[seg][fl] = arg;
+    __syncthreads();
+    if (seg == 0) {
+#pragma unroll
+        for (int s2 = 1; s2 < 4; ++s2)
+            if (s_best[s2][fl] > best) { best = s_best[s2][fl]; arg = s_arg[s2][fl]; }
+        state[f] = arg;
+    }
 }
 
 // compute_viterbi_sum: one thread per (family, node); NaN = "invalid" (root, or parent size == child size)
@@ -284,7 +298,7 @@ int reconstruct_impl(cafe_ctx* c, const cafe_params* pr, const float* root_prior
                     continue;
                 }
                 const int slot = c->slot_of[(size_t)v * c->Kmax + k];
-                hipLaunchKernelGGL(backtrack_kernel, dim3(gb), dim3(256), 0, s, c->kpool.base + (int64_t)slot * c->kpool.stride, c->kpool.ld,
+                hipLaunchKernelGGL(backtrack_kernel, dim3((unsigned)(ld / 64)), dim3(256), 0, s, c->kpool.base + (int64_t)slot * c->kpool.stride, c->kpool.ld,
                                    d_B + (int64_t)bidx[v] * pstride, ld, M, d_state + (int64_t)c->parent[v] * cols, d_state + (int64_t)v * cols);
                 HIP_TRY(c, hipGetLastError());
             }
