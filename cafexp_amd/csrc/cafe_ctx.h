@@ -59,6 +59,7 @@ struct cafe_ctx {
     int64_t panel_kstride = 0;              // doubles per category inside a panel
     int rows_pad = 0, kc = 0;
     int64_t chunk_cols = 0;
+    size_t workspace_limit = 0;             // cafe_problem::workspace_limit (0 = automatic)
     double *d_prior = nullptr, *d_logprior = nullptr, *d_catprobs = nullptr, *d_err = nullptr;
     double *d_fam_out = nullptr, *d_fam_lik = nullptr, *d_cat_out = nullptr;
     int32_t* d_failed = nullptr;

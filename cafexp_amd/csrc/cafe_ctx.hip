@@ -298,6 +298,7 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     c->rows_pad = std::max(c->kc, round_up(c->R, kBK));
     size_t free_b = 0, total_b = 0;
     HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
+    c->workspace_limit = p->workspace_limit;
     size_t budget = p->workspace_limit ? p->workspace_limit : (size_t)(free_b * 0.80);
     const size_t per_col = (size_t)c->n_panels * c->Kmax * c->rows_pad * sizeof(double);
     int64_t cols = (int64_t)(budget / per_col) / kBN * kBN;

@@ -235,7 +235,8 @@ int reconstruct_impl(cafe_ctx* c, const cafe_params* pr, const float* root_prior
     size_t free_b = 0, total_b = 0;
     HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
     const size_t per_col = (size_t)nI * rows * sizeof(double) + (size_t)n * sizeof(int32_t);
-    int64_t cols = std::min<int64_t>(c->Fp, (int64_t)((free_b * 0.8) / per_col) / kBN * kBN);
+    const size_t budget = c->workspace_limit ? c->workspace_limit : (size_t)(free_b * 0.8);
+    int64_t cols = std::min<int64_t>(c->Fp, (int64_t)(budget / per_col) / kBN * kBN);
     if (cols < kBN) { set_err(c, "cafe_reconstruct: not enough device memory for %d product panels", nI); return CAFE_ERR_MEMORY; }
     DevBuf panels, st, prior;
     if (hipMalloc(&panels.p, (size_t)nI * rows * cols * sizeof(double)) != hipSuccess || hipMalloc(&st.p, (size_t)n * cols * sizeof(int32_t)) != hipSuccess ||

@@ -199,6 +199,14 @@ def test_reconstruction_chunked_and_duplicated_families(gr):
     got = ctx.reconstruct(pr.lambdas, rp)[0]
     want = O.reconstruct(pb, pr.lambdas, rp)[0]
     _near_tie_only(pb, pr, rp, got, want, 1.0)
+    # room for one 128-column chunk only: more than 128 distinct families go through in several passes
+    pb, pr, rp, perm = _case(gr["mammals_base"])
+    whole = capi.Context(pb)
+    assert whole.stats()["n_unique_families"] > 128
+    n_interior = int((pb.leaf_taxon < 0).sum())
+    rows = (pb.max_family_size + 1 + 3) // 4 * 4
+    small = capi.Context(pb, workspace_limit=(n_interior * rows * 8 + pb.n_nodes * 4) * 128 + 64)
+    assert np.array_equal(small.reconstruct(pr.lambdas, rp)[0], whole.reconstruct(pr.lambdas, rp)[0])
 
 
 @pytest.mark.gpu
