@@ -76,8 +76,8 @@ int emit_node(cafe_ctx* c, int v, const std::vector<int>& need, PanelAlloc& pa) 
     bool init = false;
     // A parent with interior children folds (up to kMaxLeafPerOp of) its leaf children into the epilogue of
     // the first GEMM; a parent with leaf children only (a cherry) is a pure gather.  Extra leaves gather-multiply.
-    // (one leaf, and only without an error model: the specialised epilogue of prune_gemm.hip)
-    size_t fused = (inner.empty() || leaves.empty() || c->n_dev > 0) ? 0 : 1;
+    // (one leaf, without an error model or with a 3-tap one: the specialised epilogues of prune_gemm.hip)
+    size_t fused = (inner.empty() || leaves.empty() || (c->n_dev != 0 && c->n_dev != 3)) ? 0 : 1;
     for (size_t gi = 0; gi < inner.size(); ++gi) {   // child order of the reference (probability.cpp:205 walks _descendants in order)
         const int u = inner[gi];
         Op op{};
@@ -122,7 +122,7 @@ void free_device(cafe_ctx* c) {
     hipFree(c->d_counts); hipFree(c->d_weights); hipFree(c->pool.base); hipFree(c->kpool.base); hipFree(c->d_slots); hipFree(c->d_panels);
     hipFree(c->d_prior); hipFree(c->d_logprior); hipFree(c->d_catprobs); hipFree(c->d_err);
     hipFree(c->d_fam_out); hipFree(c->d_fam_lik); hipFree(c->d_cat_out); hipFree(c->d_failed);
-    hipFree(c->d_scratch); hipFree(c->d_result);
+    hipFree(c->d_scratch); hipFree(c->d_result); hipFree(c->d_stamps);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_result) hipHostFree(c->h_result);
     if (c->ev_upload) hipEventDestroy(c->ev_upload);

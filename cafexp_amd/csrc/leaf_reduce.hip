@@ -133,7 +133,11 @@ __global__ __launch_bounds__(256) void leaf_gather_fast_kernel(const GatherArgs 
     }
 #pragma unroll
     for (int rr = 0; rr < kFastRows; ++rr)
-        if (r0 + rr < a.rows_store) *reinterpret_cast<double2*>(dst + (int64_t)rr * a.ld) = v[rr];
+        if (r0 + rr < a.rows_store) {
+            // streamed once, read back by the next GEMM from HBM anyway: do not displace the matrices in L2
+            __builtin_nontemporal_store(v[rr].x, dst + (int64_t)rr * a.ld);
+            __builtin_nontemporal_store(v[rr].y, dst + (int64_t)rr * a.ld + 1);
+        }
 }
 
 template <int NLEAF, int NDEV>

@@ -43,9 +43,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 [[maybe_unused]] constexpr int kBStride = kBN + 16;                        // 144 doubles
 constexpr int a_stride(int bm) { return (bm % 32 == 16) ? bm : bm + 16; }
 
-// MI: row tile = 16*MI.  MUL: multiply into the parent panel instead of storing.  LEAF: one leaf
+// MI: row tile = 16*MI.  MUL: multiply into the parent panel instead of storing.  LEAF (0, 1 or 3 = taps): one leaf
 // sibling (no error model) is folded into the epilogue.
-template <int MI, bool MUL, bool LEAF>
+template <int MI, bool MUL, int LEAF>
 __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the body uses amdgcn-only types (buffer resource); hipcc's host pass only needs the stub
     constexpr int BM = 16 * MI;
@@ -249,14 +249,25 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
         const unsigned c_voff = (unsigned)((l4 * ldb + wave * 32 + l15) * 8);
         const int c_soff0 = ((cur.row0 + a.out_off) * ldb + cur.col0) * 8;
         __amdgpu_buffer_rsrc_t rsL = cur.rsC;
-        unsigned l_voff[2] = {0, 0};
+        constexpr int NT = LEAF == 3 ? 3 : 1;               // taps of the leaf sibling: 1, or the 3 of an error model
+        unsigned l_voff[2][NT];
+        double l_w[2][NT];                                  // error-model weights (taps outside [0, M]: weight 0, clamped column)
         int l_soff0 = 0;
         if (LEAF) {
             const int32_t* cnt = a.counts + (int64_t)a.taxon[0] * a.counts_ld + a.f0 + cur.col0 + wave * 32 + l15;
             rsL = __builtin_amdgcn_make_buffer_rsrc((void*)(a.lpool.base + (int64_t)a.leaf_slot[0][cur.cat] * a.lpool.stride), 0,
                                                     (int)(a.lpool.stride * 8), 0x00020000);
-            l_voff[0] = (unsigned)((l4 * ldl + cnt[0]) * 8);
-            l_voff[1] = (unsigned)((l4 * ldl + cnt[16]) * 8);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int x = cnt[16 * j];
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const int cc = LEAF == 3 ? x - 1 + i : x;
+                    const bool ok = LEAF != 3 || (cc >= 0 && cc <= a.max_family_size);
+                    l_voff[j][i] = (unsigned)((l4 * ldl + (ok ? cc : x)) * 8);
+                    l_w[j][i] = LEAF == 3 ? (ok ? a.err[(int64_t)x * 3 + i] : 0.0) : 1.0;
+                }
+            }
             l_soff0 = (cur.row0 + 1) * ldl * 8;             // parent size row0 + 1
         }
         const int rows_here = a.rows - cur.row0;            // valid rows of this tile (>= BM for interior tiles)
@@ -271,7 +282,13 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
                 for (int j = 0; j < 2; ++j) {
                     double f = 1.0;
                     if (ok) {
-                        if (LEAF) f = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsL, l_voff[j], l_soff0 + step * ldl * 8, 0));
+                        if (LEAF == 1) f = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsL, l_voff[j][0], l_soff0 + step * ldl * 8, 0));
+                        if (LEAF == 3) {                // sum_i err[x][i] * P_leaf[s][x - 1 + i], taps in order (leaf_reduce.hip)
+                            f = 0.0;
+#pragma unroll
+                            for (int i = 0; i < 3; ++i)
+                                f += __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsL, l_voff[j][i], l_soff0 + step * ldl * 8, 0)) * l_w[j][i];
+                        }
                         if (MUL) f *= __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(cur.rsC, c_voff, c_soff0 + (step * ldb + j * 16) * 8, 0));
                     }
                     p.f[j][r] = f;
@@ -294,14 +311,20 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
             }
         };
         auto epilogue = [&](auto full) {
-            Pre pre[2];
+            constexpr int NB = LEAF == 3 ? 1 : 2;           // the 3-tap variant has no registers left for a second set
+            Pre pre[NB];
             if (MUL || LEAF) prefetch(0, pre[0], full);
             // full unroll is mandatory: a runtime i would index the accumulator array dynamically and demote
             // it to scratch memory
 #pragma clang loop unroll(full)
             for (int i = 0; i < MI; ++i) {
-                if ((MUL || LEAF) && i + 1 < MI) prefetch(i + 1, pre[(i + 1) & 1], full);
-                flush(i, pre[i & 1], full);
+                if (NB == 2) {
+                    if ((MUL || LEAF) && i + 1 < MI) prefetch(i + 1, pre[(i + 1) & 1], full);
+                    flush(i, pre[i & (NB - 1)], full);
+                } else {
+                    flush(i, pre[0], full);
+                    if (i + 1 < MI) prefetch(i + 1, pre[0], full);
+                }
             }
         };
         unsigned long long e0 = 0;
@@ -310,15 +333,20 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
         else epilogue(std::false_type{});
         if (a.stamps) { ep_ticks += __builtin_amdgcn_s_memrealtime() - e0; n_done += 1; }
         // parent size 0 only reaches child size 0 (P[0][c] = delta(c,0)): that panel row is the child's row 0,
-        // times the leaf sibling's P_leaf[0][x] = delta(x,0)
+        // times the leaf sibling's P_leaf[0][x] = delta(x,0) (with an error model: the weight of the tap at size 0)
         if (a.out_off == 1 && cur.row_tile == 0 && tid < kBN / 2) {
             const int c2 = tid * 2;
             const double* Bp = a.src + (int64_t)cur.cat * a.panel_kstride + cur.col0 + c2;
             double2 v = *reinterpret_cast<const double2*>(Bp);
             if (LEAF) {
                 const int32_t* cnt = a.counts + (int64_t)a.taxon[0] * a.counts_ld + a.f0 + cur.col0 + c2;
-                v.x = cnt[0] == 0 ? v.x : 0.0;
-                v.y = cnt[1] == 0 ? v.y : 0.0;
+                if (LEAF == 1) {
+                    v.x = cnt[0] == 0 ? v.x : 0.0;
+                    v.y = cnt[1] == 0 ? v.y : 0.0;
+                } else {                                    // the tap that lands on size 0: err[0][1] for x = 0, err[1][0] for x = 1
+                    v.x *= cnt[0] == 0 ? a.err[1] : (cnt[0] == 1 ? a.err[3] : 0.0);
+                    v.y *= cnt[1] == 0 ? a.err[1] : (cnt[1] == 1 ? a.err[3] : 0.0);
+                }
             }
             double2* dst = reinterpret_cast<double2*>(a.dst + (int64_t)cur.cat * a.panel_kstride + cur.col0 + c2);
             if (MUL) {
@@ -354,17 +382,20 @@ int prune_gemm_pick_mi(int rows) {
 template <int MI>
 static void launch_mi(const GemmArgs& a, dim3 grid, hipStream_t stream) {
     const dim3 block(256);
+    const int leaf = a.n_leaf ? (a.err ? 3 : 1) : 0;
     if (a.mode) {
-        if (a.n_leaf) hipLaunchKernelGGL((prune_gemm_kernel<MI, true, true>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((prune_gemm_kernel<MI, true, false>), grid, block, 0, stream, a);
+        if (leaf == 3) hipLaunchKernelGGL((prune_gemm_kernel<MI, true, 3>), grid, block, 0, stream, a);
+        else if (leaf == 1) hipLaunchKernelGGL((prune_gemm_kernel<MI, true, 1>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((prune_gemm_kernel<MI, true, 0>), grid, block, 0, stream, a);
     } else {
-        if (a.n_leaf) hipLaunchKernelGGL((prune_gemm_kernel<MI, false, true>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((prune_gemm_kernel<MI, false, false>), grid, block, 0, stream, a);
+        if (leaf == 3) hipLaunchKernelGGL((prune_gemm_kernel<MI, false, 3>), grid, block, 0, stream, a);
+        else if (leaf == 1) hipLaunchKernelGGL((prune_gemm_kernel<MI, false, 1>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((prune_gemm_kernel<MI, false, 0>), grid, block, 0, stream, a);
     }
 }
 
 hipError_t launch_prune_gemm(const GemmArgs& a_in, int n_categories, hipStream_t stream) {
-    if (a_in.n_leaf > 1 || (a_in.n_leaf == 1 && a_in.err != nullptr)) return hipErrorInvalidValue;   // the schedule never asks for it
+    if (a_in.n_leaf > 1 || (a_in.n_leaf == 1 && a_in.err != nullptr && a_in.n_dev != 3)) return hipErrorInvalidValue;   // the schedule never asks for it
     GemmArgs a = a_in;
     a.n_categories = n_categories;
     // persistent grid: two workgroups per CU (what the register/LDS budget admits), a multiple of 8 so that every
