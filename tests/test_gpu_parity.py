@@ -330,6 +330,29 @@ def test_config4_shape_properties(capi, oracle):
     assert rel_err(capi.Context(doubled, max_categories=8).score(pr, alpha=2.0), 2 * whole) <= 1e-12
 
 
+def test_five_tap_error_model_and_mixed_leaf_counts(capi, oracle):
+    """cntdiff -2..2 (error_model::set_deviations is general, error_model.cpp:18-31): no fused or fast path applies,
+    the generic gather does; also a parent with three leaf children next to an interior one."""
+    tree = P.parse_newick("((A:3,B:5,C:2,(D:4,E:6):3):4,(F:6,G:1):2);")
+    species = ["A", "B", "C", "D", "E", "F", "G"]
+    rng = np.random.default_rng(11)
+    counts = rng.integers(0, 15, size=(257, 7)).astype(np.int32)
+    counts[0] = 0
+    counts[1] = [1, 0, 2, 0, 1, 0, 3]
+    pb = P.build_problem(tree, species, ["f%d" % i for i in range(257)], counts, root_filter=False, n_deviations=5)
+    rows = [[0.0, 0.0, 0.8, 0.15, 0.05], [0.0, 0.1, 0.75, 0.1, 0.05], [0.05, 0.1, 0.7, 0.1, 0.05]]
+    pr = P.Params(lambdas=np.array([0.03]), prior=P.prior_uniform(pb.max_root_family_size),
+                  error_model=P.error_model_table(rows, pb.max_family_size))
+    ctx = capi.Context(pb)
+    got, res = ctx.score(pr, per_family=True)
+    want, fam = oracle.score_base(pb, pr, per_family=True)
+    assert rel_err(got, want) <= SCORE_TOL
+    assert np.abs(res["family_lnl"] / fam - 1).max() <= VEC_TOL
+    probs, mult = oracle.discrete_gamma(3, 0.8)
+    pg = P.Params(lambdas=pr.lambdas, prior=pr.prior, multipliers=mult, cat_probs=probs, error_model=pr.error_model)
+    assert rel_err(capi.Context(pb, max_categories=3).score(pg, alpha=0.8), oracle.score_gamma(pb, pg)) <= SCORE_TOL
+
+
 def test_config5_shape_properties(capi, oracle):
     """BASELINE config 5 shape: the 100-taxon tree with a second lambda on one clade (>= 10 taxa), the default error
     model rows {0,.95,.05} / {.05,.9,.05}, base model; a family subset against the oracle plus shard additivity."""
