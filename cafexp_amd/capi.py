@@ -63,7 +63,7 @@ EXPORTS = [
     "cafe_abi_version", "cafe_create", "cafe_destroy", "cafe_last_error", "cafe_score", "cafe_score_partial",
     "cafe_finish_partial", "cafe_family_results", "cafe_get_matrix", "cafe_get_root_likelihoods", "cafe_get_stats",
     "cafe_matrix_size", "cafe_build_matrices", "cafe_probe_fp64_mfma", "cafe_set_profiling", "cafe_debug_stamps",
-    "cafe_root_max", "cafe_reconstruct", "cafe_branch_probabilities",
+    "cafe_root_max", "cafe_reconstruct", "cafe_branch_probabilities", "cafe_pvalues",
 ]
 
 _lib = None
@@ -110,6 +110,8 @@ def load():
     L.cafe_get_root_likelihoods.argtypes = [C.c_void_p, C.c_int64, C.c_int32, _f64p, C.c_size_t]
     L.cafe_root_max.restype = C.c_int
     L.cafe_root_max.argtypes = [C.c_void_p, C.POINTER(CafeParams), _f64p]
+    L.cafe_pvalues.restype = C.c_int
+    L.cafe_pvalues.argtypes = [C.c_void_p, C.POINTER(CafeParams), C.c_int32, C.c_uint64, _f64p]
     L.cafe_reconstruct.restype = C.c_int
     L.cafe_reconstruct.argtypes = [C.c_void_p, C.POINTER(CafeParams), _f32p, _i32p]
     L.cafe_branch_probabilities.restype = C.c_int
@@ -244,6 +246,17 @@ class Context:
         cp.n_categories = 1
         out = np.empty(self.n_families)
         self._check(self._lib.cafe_root_max(self._h, C.byref(cp), _p(out, _f64p)))
+        return out
+
+    def pvalues(self, lambdas, n_simulations: int = 1000, seed: int = 1) -> np.ndarray:
+        """compute_pvalues with the simulation on the device (probability.cpp:418): statistical, not draw-for-draw."""
+        lam = np.ascontiguousarray(lambdas, dtype=np.float64)
+        cp = CafeParams()
+        cp.model = CAFE_MODEL_BASE
+        cp.lambdas = _p(lam, _f64p)
+        cp.n_categories = 1
+        out = np.empty(self.n_families)
+        self._check(self._lib.cafe_pvalues(self._h, C.byref(cp), n_simulations, seed, _p(out, _f64p)))
         return out
 
     def reconstruct(self, lambdas, root_prior, multipliers=None) -> np.ndarray:

@@ -113,5 +113,12 @@ int prepare_matrices(cafe_ctx* c, const double* lambdas, const double* multiplie
 // Pupko reconstruction and Viterbi branch probabilities (reconstruct.hip)
 int reconstruct_impl(cafe_ctx* c, const cafe_params* pr, const float* root_prior, int32_t* states);
 int branch_probabilities_impl(cafe_ctx* c, const cafe_params* pr, const int32_t* sizes, double* out);
+// Device-side p-values (pvalues.hip) and what it needs from cafe_ctx.hip: a context over the same tree whose family
+// counts are written on the device, and the root-maximum prune of a context's families (-> d_fam_out, on stream s)
+constexpr int32_t kFlagDeviceCounts = 0x40000000;        // internal cafe_problem flag
+int pvalues_impl(cafe_ctx* c, const cafe_params* pr, int32_t n_simulations, uint64_t seed, double* pvalues);
+cafe_ctx* create_child_for_device_counts(const cafe_ctx* parent, int64_t n_families);
+void destroy_child(cafe_ctx* c);
+int enqueue_rootmax(cafe_ctx* c, const double* lambdas, hipStream_t s);
 
 }  // namespace cafe

@@ -132,7 +132,8 @@ void free_device(cafe_ctx* c) {
 }
 
 int create_impl(cafe_ctx* c, const cafe_problem* p) {
-    if (!p || p->n_nodes < 3 || !p->parent || !p->branch_length || !p->leaf_taxon || !p->counts) {
+    const bool device_counts = p && (p->flags & kFlagDeviceCounts);      // internal: the caller fills d_counts on the device
+    if (!p || p->n_nodes < 3 || !p->parent || !p->branch_length || !p->leaf_taxon || (!p->counts && !device_counts)) {
         set_err(c, "cafe_create: missing tree or family arrays");
         return CAFE_ERR_ARGUMENT;
     }
@@ -178,14 +179,14 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     // families: range check + de-duplication (build_reference_list, base_model.cpp:27-51)
     c->F_all = p->n_families;
     const int T = c->n_taxa;
-    for (int64_t i = 0; i < c->F_all * T; ++i)
+    for (int64_t i = 0; !device_counts && i < c->F_all * T; ++i)
         if (p->counts[i] < 0 || p->counts[i] > c->M) {
             set_err(c, "cafe_create: family %lld has a count outside [0, %d]", (long long)(i / T), c->M);
             return CAFE_ERR_ARGUMENT;
         }
     c->ref_of.resize(c->F_all);
     std::vector<int64_t> uniq;                 // first occurrence of each distinct row
-    if (p->flags & CAFE_FLAG_NO_DEDUP) {
+    if ((p->flags & CAFE_FLAG_NO_DEDUP) || device_counts) {
         uniq.resize(c->F_all);
         for (int64_t f = 0; f < c->F_all; ++f) { uniq[f] = f; c->ref_of[f] = f; }
         c->weights.assign(c->F_all, 1.0);
@@ -227,7 +228,7 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     // counts, taxon-major, padded families replicate an all-zero family
     {
         std::vector<int32_t> tm((size_t)T * c->Fp, 0);
-        for (int64_t u = 0; u < c->F_uniq; ++u)
+        for (int64_t u = 0; !device_counts && u < c->F_uniq; ++u)
             for (int t = 0; t < T; ++t) tm[(size_t)t * c->Fp + u] = p->counts[uniq[u] * T + t];
         HIP_TRY(c, hipMalloc(&c->d_counts, tm.size() * sizeof(int32_t)));
         HIP_TRY(c, hipMemcpy(c->d_counts, tm.data(), tm.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -555,6 +556,39 @@ void collect_stats(cafe_ctx* c) {
 
 }  // namespace
 
+namespace cafe {
+
+cafe_ctx* create_child_for_device_counts(const cafe_ctx* parent, int64_t n_families) {
+    cafe_ctx* c = new (std::nothrow) cafe_ctx();
+    if (!c) return nullptr;
+    cafe_problem pb{};
+    std::vector<int32_t> par(parent->parent.begin(), parent->parent.end()), lam(parent->lam_idx.begin(), parent->lam_idx.end()),
+        leaf(parent->leaf_taxon.begin(), parent->leaf_taxon.end());
+    pb.n_nodes = parent->n_nodes; pb.parent = par.data(); pb.branch_length = parent->blen.data(); pb.lambda_index = lam.data();
+    pb.leaf_taxon = leaf.data(); pb.n_taxa = parent->n_taxa; pb.n_families = n_families; pb.counts = nullptr;
+    pb.max_family_size = parent->M; pb.max_root_family_size = parent->R; pb.n_lambdas = parent->n_lambdas;
+    pb.single_lambda = parent->single_lambda; pb.max_categories = 1; pb.n_deviations = 0; pb.device = parent->device;
+    pb.flags = kFlagDeviceCounts; pb.workspace_limit = 0;
+    int rc = CAFE_ERR_MEMORY;
+    try { rc = create_impl(c, &pb); } catch (const std::exception&) { rc = CAFE_ERR_MEMORY; }
+    if (rc != CAFE_OK) { free_device(c); delete c; return nullptr; }
+    return c;
+}
+
+void destroy_child(cafe_ctx* c) {
+    if (!c) return;
+    free_device(c);
+    delete c;
+}
+
+int enqueue_rootmax(cafe_ctx* c, const double* lambdas, hipStream_t s) {
+    cafe_params pr{};
+    pr.model = CAFE_MODEL_BASE; pr.lambdas = lambdas; pr.n_categories = 1;
+    return enqueue(c, &pr, c->d_result, s, true);
+}
+
+}  // namespace cafe
+
 extern "C" {
 
 int cafe_abi_version(void) { return CAFE_ABI_VERSION; }
@@ -564,7 +598,8 @@ cafe_ctx* cafe_create(const cafe_problem* problem, char* err, size_t errlen) {
     if (!c) return nullptr;
     int rc = CAFE_ERR_ARGUMENT;
     try {
-        rc = create_impl(c, problem);
+        if (problem && (problem->flags & kFlagDeviceCounts)) { set_err(c, "cafe_create: unknown flag"); rc = CAFE_ERR_ARGUMENT; }
+        else rc = create_impl(c, problem);
     } catch (const std::exception& e) {
         set_err(c, "cafe_create: %s", e.what());
         rc = CAFE_ERR_MEMORY;
@@ -700,6 +735,16 @@ int cafe_branch_probabilities(cafe_ctx* ctx, const cafe_params* params, const in
         return branch_probabilities_impl(ctx, params, sizes, out);
     } catch (const std::exception& e) {
         set_err(ctx, "cafe_branch_probabilities: %s", e.what());
+        return CAFE_ERR_MEMORY;
+    }
+}
+
+int cafe_pvalues(cafe_ctx* ctx, const cafe_params* params, int32_t n_simulations, uint64_t seed, double* pvalues) {
+    if (!ctx) return CAFE_ERR_ARGUMENT;
+    try {
+        return pvalues_impl(ctx, params, n_simulations, seed, pvalues);
+    } catch (const std::exception& e) {
+        set_err(ctx, "cafe_pvalues: %s", e.what());
         return CAFE_ERR_MEMORY;
     }
 }

@@ -262,6 +262,9 @@ public:
     using model::model;
     ~hip_model_base() override;
     void set_device(int d) { _device = d; }
+    // compute_pvalues with the Monte-Carlo simulation on the device too (cafe_pvalues): statistical agreement with the
+    // reference's procedure, not draw for draw
+    std::vector<double> device_pvalues(int number_of_simulations, uint64_t seed);
     // compute_viterbi_sum (gene_family_reconstructor.cpp:361) for every family x node of `order` under the model's
     // plain lambda: [family][order index], NaN where the reference returns an invalid branch_probability
     std::vector<double> branch_probability_table(const reconstruction& rec, const std::vector<gene_family>& families,

@@ -31,6 +31,16 @@ std::vector<int32_t> hip_model_base::device_reconstruct(const std::vector<gene_f
     return states;
 }
 
+std::vector<double> hip_model_base::device_pvalues(int number_of_simulations, uint64_t seed) {
+    ensure_context(1);
+    std::vector<double> lambdas = _p_lambda->values(), out(_p_gene_families->size());
+    cafe_params pr{};
+    pr.model = CAFE_MODEL_BASE; pr.lambdas = lambdas.data(); pr.n_categories = 1;
+    if (cafe_pvalues(_ctx, &pr, number_of_simulations, seed, out.data()) != CAFE_OK)
+        throw std::runtime_error(std::string("cafe_pvalues: ") + cafe_last_error(_ctx));
+    return out;
+}
+
 std::vector<double> hip_model_base::branch_probability_table(const reconstruction& rec, const std::vector<gene_family>& families,
                                                              const std::vector<const clade*>& order) {
     ensure_context(1);

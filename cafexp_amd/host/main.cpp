@@ -18,7 +18,7 @@ static void usage() {
     std::fprintf(stderr,
         "usage: cafexp_hip -t TREE -i FAMILIES [-l LAMBDA | -m L1,L2,.. -y LAMBDA_TREE | -y LAMBDA_TREE] [-k K] [-a ALPHA]\n"
         "                  [-e [ERRMODEL]] [-p [POISSON_LAMBDA]] [-f ROOTDIST] [-z] [-s SEED] [-I MAXITER] [-d DEVICE] [--reps N] [--family-out FILE] [-o OUTDIR] [--limit N]\n"
-        "                  [--pvalues NSIM [--pvalues-out FILE] [--pvalues-cond FILE:K]] [--sizes M,R]\n"
+        "                  [--pvalues NSIM [--pvalues-device] [--pvalues-out FILE] [--pvalues-cond FILE:K]] [--sizes M,R]\n"
         "                  [--reconstruct [-P PVALUE]]   (with -o: the reports of reconstruction::write_results)\n");
 }
 
@@ -40,7 +40,7 @@ int main(int argc, char** argv) {
     std::string tree_path, fam_path, lambda_tree_path, multi, err_path, rootdist_path, family_out, out_dir;
     std::string pvalues_out, pvalues_cond;
     int pvalue_sims = 0, force_m = -1, force_r = -1;
-    bool do_reconstruct = false;
+    bool do_reconstruct = false, pvalues_on_device = false;
     double test_pvalue = 0.05;                                   // input_parameters::pvalue default (io.h)
     long limit = -1;
     double fixed_lambda = 0, fixed_alpha = -1, poisson = 0;
@@ -77,6 +77,7 @@ int main(int argc, char** argv) {
         }
         else if (a == "--reconstruct") do_reconstruct = true;
         else if (a == "-P") test_pvalue = std::stod(next());
+        else if (a == "--pvalues-device") pvalues_on_device = true;
         else if (a == "--pvalues") pvalue_sims = std::stoi(next());
         else if (a == "--pvalues-out") pvalues_out = next();
         else if (a == "--pvalues-cond") pvalues_cond = next();
@@ -190,15 +191,19 @@ int main(int argc, char** argv) {
         if (pvalue_sims > 0) {
             pvalue_work work;
             auto t0 = std::chrono::steady_clock::now();
-            pvalues = compute_pvalues(d.p_tree.get(), d.gene_families, mdl->get_lambda(), pvalue_sims, d.max_family_size, d.max_root_family_size,
-                                      device, &work);
+            if (pvalues_on_device)      // simulation on the GPU too: same distribution, another random sample (cafe_pvalues)
+                pvalues = mdl->device_pvalues(pvalue_sims, have_seed ? seed : 1u);
+            else
+                pvalues = compute_pvalues(d.p_tree.get(), d.gene_families, mdl->get_lambda(), pvalue_sims, d.max_family_size, d.max_root_family_size,
+                                          device, &work);
             pvalue_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (!pvalues_out.empty()) {
                 std::ofstream f(pvalues_out);
                 f.precision(17);
                 f << "#FamilyID\tpvalue\tobserved max likelihood\n";
                 for (size_t i = 0; i < pvalues.size(); ++i)
-                    f << d.gene_families[i].id() << '\t' << pvalues[i] << '\t' << work.observed_max_likelihood[i] << '\n';
+                    f << d.gene_families[i].id() << '\t' << pvalues[i] << '\t'
+                      << (work.observed_max_likelihood.empty() ? 0.0 : work.observed_max_likelihood[i]) << '\n';
             }
             if (!pvalues_cond.empty()) {                         // FILE:K -> the first K sorted conditional distributions, one per line
                 const size_t colon = pvalues_cond.rfind(':');

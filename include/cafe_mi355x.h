@@ -151,6 +151,14 @@ int cafe_family_results(cafe_ctx* ctx, const cafe_family_out* out);
  * read.  out[n_families].  cafe_family_results is not meaningful after this call. */
 int cafe_root_max(cafe_ctx* ctx, const cafe_params* params, double* out);
 
+/* compute_pvalues (probability.cpp:418-454) with the Monte-Carlo simulation on the device as well: n_simulations
+ * families per root size 0..R-1 drawn from the transition-matrix rows (set_weighted_random_family_size, :320-351)
+ * by a counter-based generator keyed by `seed`, pruned, sorted; pvalues[n_families] = max over root sizes of the
+ * upper_bound position (:379-407).  Same distribution as the reference's procedure, a different random sample: agrees
+ * with it to Monte-Carlo error, not draw for draw (the host path cafexp_amd/host/pvalues.cpp does the latter).
+ * params->lambdas is the only field read; 1 <= n_simulations <= 2048. */
+int cafe_pvalues(cafe_ctx* ctx, const cafe_params* params, int32_t n_simulations, uint64_t seed, double* pvalues);
+
 /* Ancestral reconstruction.  Pupko's joint reconstruction as reconstruct_gene_family runs it
  * (gene_family_reconstructor.cpp:13-165; base_model.cpp:145, gamma_core.cpp:301): for every category k (one for
  * the base model; lambda * multipliers[k] for the gamma model) and family f, the reconstructed size of every node

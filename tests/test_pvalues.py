@@ -159,3 +159,30 @@ def test_driver_pvalues_match_compiled_reference(gp, tmp_path, name):
     differ = np.nonzero(pv != want)[0]
     assert len(differ) <= max(1, len(want) // 100), (len(differ), pv[differ][:5], want[differ][:5])
     assert np.max(np.abs(pv - want)) <= 0.05
+
+
+@pytest.mark.gpu
+def test_device_side_simulation_agrees_statistically(gp):
+    """cafe_pvalues draws on the device (Philox keyed by the seed): a different sample of the same distribution as the
+    reference's, so agreement is statistical.  Seeds are fixed, so the numbers below are reproducible; the bounds leave
+    several standard errors of a 1000-sample tail estimate (sqrt(p(1-p)/n) <= 0.016)."""
+    from cafexp_amd import capi
+    e = gp["mammals"]
+    pb, pr = _problem(e)
+    ctx = capi.Context(pb)
+    got = ctx.pvalues(pr.lambdas, n_simulations=e["nsim"], seed=12345)
+    want = np.array(e["pvalues"])
+    d = got - want
+    assert abs(d.mean()) < 0.003 and np.abs(d).mean() < 0.005 and np.abs(d).max() < 0.08
+    assert abs(int((got < 0.05).sum()) - int((want < 0.05).sum())) <= max(3, len(want) // 50)
+    assert np.array_equal(got, ctx.pvalues(pr.lambdas, n_simulations=e["nsim"], seed=12345))      # a function of the seed only
+    other = ctx.pvalues(pr.lambdas, n_simulations=e["nsim"], seed=777)
+    assert not np.array_equal(got, other) and np.abs(got - other).mean() < 0.005
+    # the scorer still works on the same context, and so does the lambda-tree case
+    assert np.isfinite(ctx.score(pr))
+    e2 = gp["mammals_lambda_tree"]
+    pb2, pr2 = _problem(e2)
+    got2 = capi.Context(pb2).pvalues(pr2.lambdas, n_simulations=1000, seed=5)
+    assert np.abs(got2 - np.array(e2["pvalues"])).mean() < 0.02                                  # the reference used 100 simulations here
+    with pytest.raises(capi.CafeError):
+        ctx.pvalues(pr.lambdas, n_simulations=5000)
