@@ -353,6 +353,20 @@ def test_five_tap_error_model_and_mixed_leaf_counts(capi, oracle):
     assert rel_err(capi.Context(pb, max_categories=3).score(pg, alpha=0.8), oracle.score_gamma(pb, pg)) <= SCORE_TOL
 
 
+def test_three_tap_error_model_with_gamma_categories(capi, oracle, golden):
+    """The fused 3-tap leaf epilogue of K2 under several categories (every category has its own leaf matrix)."""
+    e = golden["scores"]["mammals_multilambda_err"]
+    pb, pr, _ = case_from_args(e["args"], oracle)
+    pb = dataclasses.replace(pb, counts=np.ascontiguousarray(pb.counts[:384]), family_ids=pb.family_ids[:384])
+    probs, mult = oracle.discrete_gamma(3, 1.3)
+    pg = P.Params(lambdas=np.array([0.002, 0.003]), prior=pr.prior, multipliers=mult, cat_probs=probs, error_model=pr.error_model)
+    ctx = capi.Context(pb, max_categories=3)
+    got, res = ctx.score(pg, alpha=1.3, per_family=True)
+    want, cat, fam = oracle.score_gamma(pb, pg, per_family=True)
+    assert rel_err(got, want) <= SCORE_TOL
+    assert np.abs(res["category_likelihood"] / cat - 1).max() <= VEC_TOL
+
+
 def test_config5_shape_properties(capi, oracle):
     """BASELINE config 5 shape: the 100-taxon tree with a second lambda on one clade (>= 10 taxa), the default error
     model rows {0,.95,.05} / {.05,.9,.05}, base model; a family subset against the oracle plus shard additivity."""
