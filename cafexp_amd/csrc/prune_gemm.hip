@@ -191,43 +191,25 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
             const int k1 = (kt + 1) * kBK;                  // K tile being staged into the other stage
             const bool next_full = kt + 2 < n_k;            // K tile kt+1 is another pipelined one (not the ragged last)
 #pragma unroll
-            for (int s4 = 0; s4 < 3; ++s4) {
-                if (s4 == 0 && kt == 0) stage_quarter(cur, k1, buf ^ 1, 0);       // no earlier step to carry it
-                stage_quarter(cur, k1, buf ^ 1, s4 + 1);
-                read_b(base, s4 + 1, bfr[(s4 + 1) & 1]);
+            for (int s4 = 0; s4 < 4; ++s4) {
+                if (s4 < 3) {
+                    if (s4 == 0 && kt == 0) stage_quarter(cur, k1, buf ^ 1, 0);   // no earlier step to carry it
+                    stage_quarter(cur, k1, buf ^ 1, s4 + 1);
+                } else {
+                    __syncthreads();                        // K tile kt+1 has landed; every wave has read all of K tile kt
+                    if (next_full) stage_quarter(cur, k1 + kBK, buf, 0);
+                    else if (has_next) stage_quarter(nxt, 0, buf, 0);
+                }
+                const bool pre = s4 < 3 || next_full;       // uniform
+                const double* src = s4 < 3 ? base : nbase;
+                const int ns = (s4 + 1) & 3;
+                if (pre) read_b(src, ns, bfr[(s4 + 1) & 1]);
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bfr[s4 & 1][0], acc[i][0], 0, 0, 0);
                     acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bfr[s4 & 1][1], acc[i][1], 0, 0, 0);
-                    af[i] = base[a_off + (s4 + 1) * 4 * SA + i * 16];
+                    if (pre) af[i] = src[a_off + ns * 4 * SA + i * 16];
                     __builtin_amdgcn_sched_barrier(0);      // keep "two MFMAs, then the read that reuses their register"
-                }
-            }
-            {   // step 3: its fragments are in registers already.  The first kHead row blocks go to the matrix pipe before
-                // the barrier, so the wait for the other waves (and for this wave's DMA) is covered by queued MFMAs; the
-                // reads of the next tile's first fragments follow the barrier.
-                constexpr int kHead = MI >= 6 ? MI - 3 : MI / 2;
-#pragma unroll
-                for (int i = 0; i < kHead; ++i) {
-                    acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bfr[1][0], acc[i][0], 0, 0, 0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bfr[1][1], acc[i][1], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                __syncthreads();                            // K tile kt+1 has landed; every wave has read all of K tile kt
-                if (next_full) stage_quarter(cur, k1 + kBK, buf, 0);
-                else if (has_next) stage_quarter(nxt, 0, buf, 0);
-                if (next_full) {                            // uniform
-                    read_b(nbase, 0, bfr[0]);
-#pragma unroll
-                    for (int i = 0; i < kHead; ++i) af[i] = nbase[a_off + i * 16];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = kHead; i < MI; ++i) {
-                    acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bfr[1][0], acc[i][0], 0, 0, 0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bfr[1][1], acc[i][1], 0, 0, 0);
-                    if (next_full) af[i] = nbase[a_off + i * 16];
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             ++g;
