@@ -14,7 +14,9 @@
 namespace cafe {
 
 struct Op {
-    int type;                   // 0 gather, 1 gemm
+    int type;                   // 0 gather, 1 gemm, 2 combine (gather the columns of a factor panel into the parent's)
+    int parent;                 // node whose panel is written (for a factor GEMM: the node the factor belongs to)
+    bool to_factor;             // gemm: plain store of P_child . L_child over the CHILD's distinct columns
     int dst_panel;
     int src_panel;              // gemm
     int child;                  // gemm: child node (its branch's matrix)
@@ -42,6 +44,13 @@ struct cafe_ctx {
 
     // schedule
     std::vector<cafe::Op> ops;
+    // subtree-level de-duplication: a node's panel has one column per distinct pattern of leaf counts UNDER that node
+    bool subtree_dedup = false;
+    std::vector<int64_t> pat_cols;           // [n_nodes] padded distinct patterns of an interior node (0 for leaves)
+    std::vector<char> edge_identity;         // [n_nodes] interior child whose columns are its parent's, in order
+    std::vector<int32_t*> d_edge_map;        // [n_nodes] interior child: its column for every column of the parent
+    std::vector<int32_t*> d_leaf_cnt;        // [n_nodes] interior parent: [its leaf children][its columns] observed counts
+    std::vector<int> leaf_rank;              // [n_nodes] leaf: its row in the parent's d_leaf_cnt table
     int n_panels = 0, root_panel = -1;
 
     // device state

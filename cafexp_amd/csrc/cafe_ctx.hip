@@ -77,26 +77,50 @@ int emit_node(cafe_ctx* c, int v, const std::vector<int>& need, PanelAlloc& pa) 
     // A parent with interior children folds (up to kMaxLeafPerOp of) its leaf children into the epilogue of
     // the first GEMM; a parent with leaf children only (a cherry) is a pure gather.  Extra leaves gather-multiply.
     // (one leaf, without an error model or with a 3-tap one: the specialised epilogues of prune_gemm.hip)
-    size_t fused = (inner.empty() || leaves.empty() || (c->n_dev != 0 && c->n_dev != 3)) ? 0 : 1;
+    // A child with fewer distinct columns than its parent (subtree-level de-duplication) first gets its factor
+    // P . L over ITS columns in a scratch panel, which a combine pass spreads over the parent's columns.
+    const bool first_direct = !inner.empty() && (!c->subtree_dedup || c->edge_identity[inner[0]]);
+    size_t fused = (!first_direct || leaves.empty() || (c->n_dev != 0 && c->n_dev != 3)) ? 0 : 1;
     for (size_t gi = 0; gi < inner.size(); ++gi) {   // child order of the reference (probability.cpp:205 walks _descendants in order)
         const int u = inner[gi];
+        const bool direct = !c->subtree_dedup || c->edge_identity[u];
         Op op{};
         op.type = 1;
-        op.dst_panel = dst;
+        op.parent = v;
         op.src_panel = panel_of[u];
         op.child = u;
-        op.mode = init ? 1 : 0;
         op.to_root = (v == c->root);
-        if (gi == 0) {
-            op.n_leaf = (int)fused;
-            for (size_t l = 0; l < fused; ++l) op.leaf_node[l] = leaves[l];
+        if (direct) {
+            op.dst_panel = dst;
+            op.mode = init ? 1 : 0;
+            if (gi == 0) {
+                op.n_leaf = (int)fused;
+                for (size_t l = 0; l < fused; ++l) op.leaf_node[l] = leaves[l];
+            }
+            c->ops.push_back(op);
+        } else {
+            const int scratch = pa.get();
+            op.dst_panel = scratch;
+            op.mode = 0;
+            op.to_factor = true;
+            c->ops.push_back(op);
+            Op cb{};
+            cb.type = 2;
+            cb.parent = v;
+            cb.dst_panel = dst;
+            cb.src_panel = scratch;
+            cb.child = u;
+            cb.mode = init ? 1 : 0;
+            cb.to_root = (v == c->root);
+            c->ops.push_back(cb);
+            pa.put(scratch);
         }
-        c->ops.push_back(op);
         init = true;
     }
     for (size_t i = fused; i < leaves.size(); i += kMaxLeafPerOp) {
         Op op{};
         op.type = 0;
+        op.parent = v;
         op.dst_panel = dst;
         op.n_leaf = (int)std::min<size_t>(kMaxLeafPerOp, leaves.size() - i);
         for (int l = 0; l < op.n_leaf; ++l) op.leaf_node[l] = leaves[i + l];
@@ -107,6 +131,69 @@ int emit_node(cafe_ctx* c, int v, const std::vector<int>& need, PanelAlloc& pa) 
     }
     for (int u : inner) pa.put(panel_of[u]);
     return dst;
+}
+
+// Subtree-level de-duplication (host side, once): the distinct patterns of leaf counts under every interior node, the
+// column of each child for every column of its parent, and the leaf children's counts per parent column.  Columns are
+// numbered by first occurrence in (distinct-)family order, so the root's columns are the distinct families themselves
+// and a child with as many patterns as its parent has them in the same order (an identity map: no combine pass).
+int compute_patterns(cafe_ctx* c, const cafe_problem* p, const std::vector<int64_t>& uniq) {
+    const int n = c->n_nodes, T = c->n_taxa;
+    const int64_t F = c->F_uniq;
+    c->pat_cols.assign(n, 0);
+    c->edge_identity.assign(n, 0);
+    c->d_edge_map.assign(n, nullptr);
+    c->d_leaf_cnt.assign(n, nullptr);
+    c->leaf_rank.assign(n, 0);
+    std::vector<std::vector<int32_t>> pid(n);            // [interior node][distinct family] pattern index
+    std::vector<std::vector<int64_t>> rep(n);            // [interior node][pattern] first distinct family showing it
+    for (int v = 0; v < n; ++v) {
+        if (c->leaf_taxon[v] >= 0) continue;
+        std::vector<int> inner, leaves;
+        for (int u : c->children[v]) (c->leaf_taxon[u] < 0 ? inner : leaves).push_back(u);
+        const size_t kw = inner.size() + leaves.size();
+        std::unordered_map<std::string, int32_t> seen;
+        seen.reserve((size_t)F * 2);
+        pid[v].resize(F);
+        std::vector<int32_t> key(kw);
+        for (int64_t f = 0; f < F; ++f) {
+            size_t k = 0;
+            for (int u : inner) key[k++] = pid[u][f];
+            for (int u : leaves) key[k++] = p->counts[uniq[f] * T + c->leaf_taxon[u]];
+            std::string ks(reinterpret_cast<const char*>(key.data()), sizeof(int32_t) * kw);
+            if (v == c->root) {                          // the root keeps one column per family of the context (K4 reads them
+                pid[v][f] = (int32_t)f;                  // by family index), also when identical families were kept apart
+                rep[v].push_back(f);
+                continue;
+            }
+            auto it = seen.find(ks);
+            if (it == seen.end()) {
+                it = seen.emplace(std::move(ks), (int32_t)rep[v].size()).first;
+                rep[v].push_back(f);
+            }
+            pid[v][f] = it->second;
+        }
+        const int64_t U = (int64_t)rep[v].size(), Up = round_up64(U, kBN);
+        c->pat_cols[v] = Up;
+        for (size_t l = 0; l < leaves.size(); ++l) c->leaf_rank[leaves[l]] = (int)l;
+        if (!leaves.empty()) {
+            std::vector<int32_t> tab(leaves.size() * (size_t)Up, 0);
+            for (size_t l = 0; l < leaves.size(); ++l)
+                for (int64_t u2 = 0; u2 < U; ++u2) tab[l * Up + u2] = p->counts[uniq[rep[v][u2]] * T + c->leaf_taxon[leaves[l]]];
+            HIP_TRY(c, hipMalloc(&c->d_leaf_cnt[v], tab.size() * sizeof(int32_t)));
+            HIP_TRY(c, hipMemcpy(c->d_leaf_cnt[v], tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        for (int u : inner) {
+            const int64_t Uc = (int64_t)rep[u].size();
+            if (Uc == U) { c->edge_identity[u] = 1; continue; }    // first-occurrence numbering on both sides: same order
+            std::vector<int32_t> map((size_t)Up, 0);
+            for (int64_t u2 = 0; u2 < U; ++u2) map[u2] = pid[u][rep[v][u2]];
+            HIP_TRY(c, hipMalloc(&c->d_edge_map[u], map.size() * sizeof(int32_t)));
+            HIP_TRY(c, hipMemcpy(c->d_edge_map[u], map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        for (int u : inner) { std::vector<int32_t>().swap(pid[u]); }   // children are not needed again
+    }
+    return CAFE_OK;
 }
 
 // matrix_cache_key (matrix_cache.h:42-61)
@@ -123,6 +210,8 @@ void free_device(cafe_ctx* c) {
     hipFree(c->d_prior); hipFree(c->d_logprior); hipFree(c->d_catprobs); hipFree(c->d_err);
     hipFree(c->d_fam_out); hipFree(c->d_fam_lik); hipFree(c->d_cat_out); hipFree(c->d_failed);
     hipFree(c->d_scratch); hipFree(c->d_result); hipFree(c->d_stamps);
+    for (auto ptr : c->d_edge_map) hipFree(ptr);
+    for (auto ptr : c->d_leaf_cnt) hipFree(ptr);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_result) hipHostFree(c->h_result);
     if (c->ev_upload) hipEventDestroy(c->ev_upload);
@@ -210,13 +299,6 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     c->F_uniq = (int64_t)uniq.size();
     c->Fp = round_up64(c->F_uniq, kBN);
 
-    // schedule
-    std::vector<int> need(c->n_nodes, 0);
-    panel_need(c, c->root, need);
-    PanelAlloc pa;
-    c->root_panel = emit_node(c, c->root, need, pa);
-    c->n_panels = pa.high;
-
     // device
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_err(c, "cafe_create: no HIP device available (this library has no CPU path)"); return CAFE_ERR_DEVICE; }
@@ -236,6 +318,17 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
         std::copy(c->weights.begin(), c->weights.end(), w.begin());
         HIP_TRY(c, hipMalloc(&c->d_weights, w.size() * sizeof(double)));
         HIP_TRY(c, hipMemcpy(c->d_weights, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+
+    // subtree-level de-duplication tables, then the schedule (which depends on them)
+    c->subtree_dedup = !device_counts && !(p->flags & CAFE_FLAG_NO_SUBTREE_DEDUP);
+    if (c->subtree_dedup) { const int rc = compute_patterns(c, p, uniq); if (rc != CAFE_OK) return rc; }
+    std::vector<int> need(c->n_nodes, 0);
+    panel_need(c, c->root, need);
+    {
+        PanelAlloc pa;
+        c->root_panel = emit_node(c, c->root, need, pa);
+        c->n_panels = pa.high;
     }
 
     // matrix pools: one slot per (branch, category); distinct quantized keys share a slot per call.
@@ -307,6 +400,15 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     cols = std::min<int64_t>(cols, (int64_t)(0xFFFFFFF0ll / ((int64_t)c->rows_pad * 8)) / kBN * kBN);
     if (cols < kBN) { set_err(c, "cafe_create: %zu bytes of workspace cannot hold %d panels of one 128-family tile", budget, c->n_panels); return CAFE_ERR_MEMORY; }
     c->chunk_cols = std::min<int64_t>(cols, c->Fp);
+    if (c->subtree_dedup && c->chunk_cols < c->Fp) {
+        // several column chunks: the per-node column maps address whole panels, so this case keeps one column per
+        // family in every panel (the schedule without combine passes needs no more panels than the one with them)
+        c->subtree_dedup = false;
+        c->ops.clear();
+        PanelAlloc pa;
+        c->root_panel = emit_node(c, c->root, need, pa);
+        c->n_panels = pa.high;
+    }
     c->panel_kstride = (int64_t)c->rows_pad * c->chunk_cols;
     c->panel_stride = c->panel_kstride * c->Kmax;
     const size_t panel_bytes = (size_t)c->n_panels * c->panel_stride * sizeof(double);
@@ -478,20 +580,31 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bo
     c->gemm_ev_used = 0;
     for (int64_t f0 = 0; f0 < c->Fp; f0 += c->chunk_cols) {
         const int64_t cols = std::min<int64_t>(c->chunk_cols, c->Fp - f0);
+        // columns (and leading dimension) of a node's panel: one per distinct leaf-count pattern under it, or the chunk
+        auto cols_of = [&](int v) -> int64_t { return c->subtree_dedup ? c->pat_cols[v] : cols; };
         for (const Op& op : c->ops) {
             const int rows = op.to_root ? c->R : c->M + 1;
             const int rows_store = op.to_root ? c->R : c->kc;
             double* dst = c->d_panels + (int64_t)op.dst_panel * c->panel_stride;
-            if (op.type == 0) {
+            // the leaf children's observed counts per column of the parent's panel
+            const int32_t* cnt_base = c->subtree_dedup ? c->d_leaf_cnt[op.parent] : c->d_counts;
+            const int64_t cnt_ld = c->subtree_dedup ? c->pat_cols[op.parent] : c->Fp;
+            const int64_t cnt_f0 = c->subtree_dedup ? 0 : f0;
+            auto cnt_row = [&](int leaf) { return c->subtree_dedup ? c->leaf_rank[leaf] : c->leaf_taxon[leaf]; };
+            if (op.type == 2) {
+                const int64_t pc = cols_of(op.parent), cc = cols_of(op.child);
+                HIP_TRY(c, launch_combine(dst, pc, c->d_panels + (int64_t)op.src_panel * c->panel_stride, cc, c->d_edge_map[op.child], rows, pc,
+                                          c->panel_kstride, K, op.mode, s));
+            } else if (op.type == 0) {
                 GatherArgs g{};
                 g.pool = c->pool;
                 g.n_leaf = op.n_leaf;
                 for (int l = 0; l < op.n_leaf; ++l) {
-                    g.taxon[l] = c->leaf_taxon[op.leaf_node[l]];
+                    g.taxon[l] = cnt_row(op.leaf_node[l]);
                     for (int k = 0; k < K; ++k) g.slot[l][k] = c->slot_of[(size_t)op.leaf_node[l] * c->Kmax + k];
                 }
-                g.counts = c->d_counts; g.counts_ld = c->Fp; g.f0 = f0;
-                g.dst = dst; g.panel_kstride = c->panel_kstride; g.ld = (int)cols;
+                g.counts = cnt_base; g.counts_ld = cnt_ld; g.f0 = cnt_f0;
+                g.dst = dst; g.panel_kstride = c->panel_kstride; g.ld = (int)cols_of(op.parent);
                 g.row_off = op.to_root ? 1 : 0; g.rows = rows; g.rows_store = rows_store; g.mode = op.mode;
                 g.err = use_err ? c->d_err : nullptr; g.n_dev = use_err ? c->n_dev : 0; g.max_family_size = c->M;
                 HIP_TRY(c, launch_leaf_gather(g, K, s));
@@ -500,29 +613,30 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bo
                 g.pool = c->kpool;
                 for (int k = 0; k < K; ++k) g.slot[k] = c->slot_of[(size_t)op.child * c->Kmax + k];
                 g.src = c->d_panels + (int64_t)op.src_panel * c->panel_stride;
-                g.dst = dst; g.panel_kstride = c->panel_kstride; g.ld = (int)cols; g.k_valid = c->M + 1;
+                const int64_t gc = cols_of(op.child);       // the GEMM runs over the child's columns (= the parent's when direct)
+                g.dst = dst; g.panel_kstride = c->panel_kstride; g.ld = (int)gc; g.k_valid = c->M + 1;
                 g.rows = op.to_root ? c->R : c->M;           // parent sizes 1..rows
                 g.out_off = op.to_root ? 0 : 1;
                 g.mode = op.mode;
                 g.mi = prune_gemm_pick_mi(g.rows);
                 g.n_row_tiles = (g.rows + 16 * g.mi - 1) / (16 * g.mi);
-                g.n_col_tiles = (int)(cols / kBN);
+                g.n_col_tiles = (int)(gc / kBN);
                 { const char* sl = std::getenv("CAFE_GEMM_STAMPS_LAUNCH"); const long want = sl ? std::atol(sl) : -1;
                   g.stamps = (want < 0 || want == (long)c->stats.gemm_launches) ? c->d_stamps : nullptr; }
                 g.lpool = c->pool;
                 g.n_leaf = op.n_leaf;
                 for (int l = 0; l < op.n_leaf; ++l) {
-                    g.taxon[l] = c->leaf_taxon[op.leaf_node[l]];
+                    g.taxon[l] = cnt_row(op.leaf_node[l]);
                     for (int k = 0; k < K; ++k) g.leaf_slot[l][k] = c->slot_of[(size_t)op.leaf_node[l] * c->Kmax + k];
                 }
-                g.counts = c->d_counts; g.counts_ld = c->Fp; g.f0 = f0;
+                g.counts = cnt_base; g.counts_ld = cnt_ld; g.f0 = cnt_f0;
                 g.err = use_err ? c->d_err : nullptr; g.n_dev = use_err ? c->n_dev : 0; g.max_family_size = c->M;
                 if (c->profile && c->gemm_ev_used + 2 <= c->gemm_ev.size()) HIP_TRY(c, hipEventRecord(c->gemm_ev[c->gemm_ev_used++], s));
                 HIP_TRY(c, launch_prune_gemm(g, K, s));
                 if (c->profile && c->gemm_ev_used + 1 <= c->gemm_ev.size()) HIP_TRY(c, hipEventRecord(c->gemm_ev[c->gemm_ev_used++], s));
                 c->stats.gemm_launches += 1;
-                c->stats.gemm_flops += 2.0 * rows * (c->M + 1) * (double)cols * K;
-                c->stats.gemm_bytes += 8.0 * K * ((double)rows * (c->M + 1) + (double)(c->M + 1) * cols + (double)rows * cols);
+                c->stats.gemm_flops += 2.0 * rows * (c->M + 1) * (double)gc * K;
+                c->stats.gemm_bytes += 8.0 * K * ((double)rows * (c->M + 1) + (double)(c->M + 1) * gc + (double)rows * gc);
             }
         }
         if (c->profile && f0 + c->chunk_cols >= c->Fp) HIP_TRY(c, hipEventRecord(c->ev[2], s));

@@ -160,6 +160,45 @@ hipError_t launch_leaf_gather(const GatherArgs& a, int n_categories, hipStream_t
     return hipGetLastError();
 }
 
+// Subtree-level de-duplication: families that agree on every leaf under a node share that node's likelihood column,
+// so a child's panel (and the GEMM over it) has one column per DISTINCT pattern below the child; the parent's
+// columns pick theirs up through an index map.  Same arithmetic per column as without the de-duplication.
+__global__ __launch_bounds__(256) void combine_kernel(double* __restrict__ dst, int64_t ld_dst, const double* __restrict__ src, int64_t ld_src,
+                                                      const int32_t* __restrict__ map, int rows, int64_t cols, int64_t kstride, int mode) {
+    const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (u >= cols) return;
+    const int r0 = blockIdx.y * 8;
+    const int32_t m0 = map[u], m1 = map[u + 1];
+    const double* s = src + (int64_t)blockIdx.z * kstride;
+    double* d = dst + (int64_t)blockIdx.z * kstride + u;
+    double2 v[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int r = r0 + rr;
+        v[rr] = make_double2(0.0, 0.0);
+        if (r < rows) {
+            v[rr].x = s[(int64_t)r * ld_src + m0];
+            v[rr].y = s[(int64_t)r * ld_src + m1];
+            if (mode) {
+                const double2 old = *reinterpret_cast<const double2*>(d + (int64_t)r * ld_dst);
+                v[rr].x *= old.x;
+                v[rr].y *= old.y;
+            }
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+        if (r0 + rr < rows) *reinterpret_cast<double2*>(d + (int64_t)(r0 + rr) * ld_dst) = v[rr];
+}
+
+hipError_t launch_combine(double* dst, int64_t ld_dst, const double* src, int64_t ld_src, const int32_t* map, int rows, int64_t cols,
+                          int64_t panel_kstride, int n_categories, int mode, hipStream_t stream) {
+    (void)hipGetLastError();
+    dim3 grid((unsigned)((cols / 2 + 255) / 256), (unsigned)((rows + 7) / 8), (unsigned)n_categories);
+    hipLaunchKernelGGL(combine_kernel, grid, dim3(256), 0, stream, dst, ld_dst, src, ld_src, map, rows, cols, panel_kstride, mode);
+    return hipGetLastError();
+}
+
 // One thread per family; rows of the root panel are read coalesced along the family axis.
 __global__ __launch_bounds__(256) void root_reduce_kernel(const ReduceArgs a) {
     const int64_t fl = (int64_t)blockIdx.x * 256 + threadIdx.x;

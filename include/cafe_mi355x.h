@@ -78,6 +78,9 @@ typedef struct cafe_problem {
 
 #define CAFE_FLAG_NO_DEDUP 1         /* keep identical families separate (build_reference_list, base_model.cpp:27,
                                         collapses them; values are identical either way) */
+#define CAFE_FLAG_NO_SUBTREE_DEDUP 2 /* one panel column per family at every node, instead of one per distinct pattern of
+                                        leaf counts under the node (the same sharing as build_reference_list, applied per
+                                        subtree; values are identical either way) */
 
 enum { CAFE_MODEL_BASE = 0, CAFE_MODEL_GAMMA = 1 };
 
