@@ -14,7 +14,7 @@
 namespace cafe {
 
 struct Op {
-    int type;                   // 0 gather, 1 gemm, 2 combine (gather the columns of a factor panel into the parent's)
+    int type;                   // 0 assemble (leaf gathers and/or factor panels of de-duplicated children), 1 gemm
     int parent;                 // node whose panel is written (for a factor GEMM: the node the factor belongs to)
     bool to_factor;             // gemm: plain store of P_child . L_child over the CHILD's distinct columns
     int dst_panel;
@@ -23,6 +23,9 @@ struct Op {
     int n_leaf;                 // gather
     int leaf_node[kMaxLeafPerOp];
     int mode;                   // 0 store, 1 multiply
+    int n_src;                  // assemble: factor panels folded in (children with fewer distinct columns than the parent)
+    int src_child[2];
+    int src_panels[2];
     bool to_root;
 };
 

@@ -81,6 +81,7 @@ int emit_node(cafe_ctx* c, int v, const std::vector<int>& need, PanelAlloc& pa) 
     // P . L over ITS columns in a scratch panel, which a combine pass spreads over the parent's columns.
     const bool first_direct = !inner.empty() && (!c->subtree_dedup || c->edge_identity[inner[0]]);
     size_t fused = (!first_direct || leaves.empty() || (c->n_dev != 0 && c->n_dev != 3)) ? 0 : 1;
+    std::vector<std::pair<int, int>> factors;             // (child, scratch panel) waiting to be assembled
     for (size_t gi = 0; gi < inner.size(); ++gi) {   // child order of the reference (probability.cpp:205 walks _descendants in order)
         const int u = inner[gi];
         const bool direct = !c->subtree_dedup || c->edge_identity[u];
@@ -98,37 +99,36 @@ int emit_node(cafe_ctx* c, int v, const std::vector<int>& need, PanelAlloc& pa) 
                 for (size_t l = 0; l < fused; ++l) op.leaf_node[l] = leaves[l];
             }
             c->ops.push_back(op);
+            init = true;
         } else {
             const int scratch = pa.get();
             op.dst_panel = scratch;
             op.mode = 0;
             op.to_factor = true;
             c->ops.push_back(op);
-            Op cb{};
-            cb.type = 2;
-            cb.parent = v;
-            cb.dst_panel = dst;
-            cb.src_panel = scratch;
-            cb.child = u;
-            cb.mode = init ? 1 : 0;
-            cb.to_root = (v == c->root);
-            c->ops.push_back(cb);
-            pa.put(scratch);
+            factors.emplace_back(u, scratch);
         }
-        init = true;
     }
-    for (size_t i = fused; i < leaves.size(); i += kMaxLeafPerOp) {
+    // assemble the parent's panel: up to two factor panels and two leaf children per pass, written once
+    size_t li = fused, fi = 0;
+    while (li < leaves.size() || fi < factors.size()) {
         Op op{};
         op.type = 0;
         op.parent = v;
         op.dst_panel = dst;
-        op.n_leaf = (int)std::min<size_t>(kMaxLeafPerOp, leaves.size() - i);
-        for (int l = 0; l < op.n_leaf; ++l) op.leaf_node[l] = leaves[i + l];
-        op.mode = init ? 1 : 0;
         op.to_root = (v == c->root);
+        const size_t max_leaf = factors.empty() ? (size_t)kMaxLeafPerOp : 2;     // the fast kernel takes two of each
+        op.n_leaf = (int)std::min<size_t>(max_leaf, leaves.size() - li);
+        for (int l = 0; l < op.n_leaf; ++l) op.leaf_node[l] = leaves[li + l];
+        li += op.n_leaf;
+        op.n_src = (int)std::min<size_t>(2, factors.size() - fi);
+        for (int j = 0; j < op.n_src; ++j) { op.src_child[j] = factors[fi + j].first; op.src_panels[j] = factors[fi + j].second; }
+        fi += op.n_src;
+        op.mode = init ? 1 : 0;
         c->ops.push_back(op);
         init = true;
     }
+    for (auto& fs : factors) pa.put(fs.second);
     for (int u : inner) pa.put(panel_of[u]);
     return dst;
 }
@@ -591,11 +591,7 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bo
             const int64_t cnt_ld = c->subtree_dedup ? c->pat_cols[op.parent] : c->Fp;
             const int64_t cnt_f0 = c->subtree_dedup ? 0 : f0;
             auto cnt_row = [&](int leaf) { return c->subtree_dedup ? c->leaf_rank[leaf] : c->leaf_taxon[leaf]; };
-            if (op.type == 2) {
-                const int64_t pc = cols_of(op.parent), cc = cols_of(op.child);
-                HIP_TRY(c, launch_combine(dst, pc, c->d_panels + (int64_t)op.src_panel * c->panel_stride, cc, c->d_edge_map[op.child], rows, pc,
-                                          c->panel_kstride, K, op.mode, s));
-            } else if (op.type == 0) {
+            if (op.type == 0) {
                 GatherArgs g{};
                 g.pool = c->pool;
                 g.n_leaf = op.n_leaf;
@@ -607,6 +603,12 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bo
                 g.dst = dst; g.panel_kstride = c->panel_kstride; g.ld = (int)cols_of(op.parent);
                 g.row_off = op.to_root ? 1 : 0; g.rows = rows; g.rows_store = rows_store; g.mode = op.mode;
                 g.err = use_err ? c->d_err : nullptr; g.n_dev = use_err ? c->n_dev : 0; g.max_family_size = c->M;
+                g.n_src = op.n_src;
+                for (int j = 0; j < op.n_src; ++j) {
+                    g.src[j] = c->d_panels + (int64_t)op.src_panels[j] * c->panel_stride;
+                    g.ld_src[j] = cols_of(op.src_child[j]);
+                    g.map[j] = c->d_edge_map[op.src_child[j]];
+                }
                 HIP_TRY(c, launch_leaf_gather(g, K, s));
             } else {
                 GemmArgs g{};

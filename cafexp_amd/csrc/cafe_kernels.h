@@ -93,6 +93,12 @@ struct GatherArgs {
     const double* err;              // [(M+1)][n_dev] or nullptr
     int32_t n_dev;
     int32_t max_family_size;        // M
+    // factor panels of interior children that have fewer distinct columns than this parent (subtree-level
+    // de-duplication): column f of the parent takes column map[j][f] of factor j
+    int32_t n_src;
+    const double* src[2];
+    int64_t ld_src[2];
+    const int32_t* map[2];
 };
 
 struct ReduceArgs {
@@ -120,9 +126,6 @@ hipError_t launch_prune_gemm(const GemmArgs& a, int n_categories, hipStream_t st
 int prune_gemm_pick_mi(int rows);     // row-tile height (in 16-row blocks) with the least padding
 hipError_t launch_leaf_gather(const GatherArgs& a, int n_categories, hipStream_t stream);
 hipError_t launch_root_reduce(const ReduceArgs& a, hipStream_t stream);
-// dst[k][row][u] (op)= src[k][row][map[u]], u < cols, row < rows: the parent's columns gather the child's distinct ones
-hipError_t launch_combine(double* dst, int64_t ld_dst, const double* src, int64_t ld_src, const int32_t* map, int rows, int64_t cols,
-                          int64_t panel_kstride, int n_categories, int mode, hipStream_t stream);
 // sum_f w_f * fam_out[f] and the number of failed families -> out[0], out[1]
 hipError_t launch_final_sum(const double* fam_out, const double* weights, const int32_t* failed, int64_t n,
                             double* scratch, int n_scratch, double* out, hipStream_t stream);

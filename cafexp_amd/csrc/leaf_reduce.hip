@@ -61,6 +61,8 @@ __global__ __launch_bounds__(256) void leaf_gather_kernel(const GatherArgs a) {
                     v *= fac;
                 }
             }
+            for (int j = 0; j < a.n_src; ++j)
+                v *= a.src[j][(int64_t)cat * a.panel_kstride + (int64_t)r * a.ld_src[j] + a.map[j][f]];
             if (a.mode) v *= dst[(int64_t)r * a.ld];
         }
         dst[(int64_t)r * a.ld] = v;
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256) void leaf_gather_kernel(const GatherArgs a) {
 // clamped column instead of a branch: fac = sum_i err[x][i] * P[s][x - half + i] in the reference's tap order
 // (probability.cpp:187-196 builds the leaf vector, matrix_cache.cpp:28 multiplies it).
 constexpr int kFastRows = 8;
-template <int NLEAF, int NDEV, bool MUL>
+template <int NLEAF, int NDEV, bool MUL, int NSRC>
 __global__ __launch_bounds__(256) void leaf_gather_fast_kernel(const GatherArgs a) {
     const int cat = blockIdx.z;
     const int f = (blockIdx.x * 256 + threadIdx.x) * 2;
@@ -81,9 +83,18 @@ __global__ __launch_bounds__(256) void leaf_gather_fast_kernel(const GatherArgs 
     const int r0 = blockIdx.y * kFastRows;
     const unsigned ldp = (unsigned)a.pool.ld;
     double* __restrict__ dst = a.dst + (int64_t)cat * a.panel_kstride + (int64_t)r0 * a.ld + f;
-    unsigned o0[NLEAF][NDEV], o1[NLEAF][NDEV];
-    double w0[NLEAF][NDEV], w1[NLEAF][NDEV];
-    const double* P[NLEAF];
+    constexpr int NL = NLEAF > 0 ? NLEAF : 1;               // (zero-length arrays are not allowed)
+    unsigned o0[NL][NDEV], o1[NL][NDEV];
+    double w0[NL][NDEV], w1[NL][NDEV];
+    const double* P[NL];
+    const double* S[NSRC > 0 ? NSRC : 1];                   // factor panels, row r0 of this category
+    unsigned m0[NSRC > 0 ? NSRC : 1], m1[NSRC > 0 ? NSRC : 1];
+#pragma unroll
+    for (int j = 0; j < NSRC; ++j) {
+        S[j] = a.src[j] + (int64_t)cat * a.panel_kstride + (int64_t)r0 * a.ld_src[j];
+        m0[j] = (unsigned)a.map[j][f];
+        m1[j] = (unsigned)a.map[j][f + 1];
+    }
     constexpr int half = (NDEV - 1) / 2;
 #pragma unroll
     for (int l = 0; l < NLEAF; ++l) {
@@ -123,6 +134,12 @@ __global__ __launch_bounds__(256) void leaf_gather_fast_kernel(const GatherArgs 
                     y *= fy;
                 }
             }
+#pragma unroll
+            for (int j = 0; j < NSRC; ++j) {
+                const double* row = S[j] + (int64_t)rr * a.ld_src[j];
+                x *= row[m0[j]];
+                y *= row[m1[j]];
+            }
             if (MUL) {
                 const double2 old = *reinterpret_cast<const double2*>(dst + (int64_t)rr * a.ld);
                 x *= old.x;
@@ -140,62 +157,31 @@ __global__ __launch_bounds__(256) void leaf_gather_fast_kernel(const GatherArgs 
         }
 }
 
+template <int NLEAF, int NDEV, int NSRC>
+static void launch_fast3(const GatherArgs& a, dim3 grid, hipStream_t stream) {
+    if (a.mode) hipLaunchKernelGGL((leaf_gather_fast_kernel<NLEAF, NDEV, true, NSRC>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((leaf_gather_fast_kernel<NLEAF, NDEV, false, NSRC>), grid, dim3(256), 0, stream, a);
+}
 template <int NLEAF, int NDEV>
 static void launch_fast(const GatherArgs& a, dim3 grid, hipStream_t stream) {
-    if (a.mode) hipLaunchKernelGGL((leaf_gather_fast_kernel<NLEAF, NDEV, true>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((leaf_gather_fast_kernel<NLEAF, NDEV, false>), grid, dim3(256), 0, stream, a);
+    if (a.n_src == 0) { if (NLEAF > 0) launch_fast3<(NLEAF > 0 ? NLEAF : 1), NDEV, 0>(a, grid, stream); }
+    else if (a.n_src == 1) launch_fast3<NLEAF, NDEV, 1>(a, grid, stream);
+    else launch_fast3<NLEAF, NDEV, 2>(a, grid, stream);
 }
 
 hipError_t launch_leaf_gather(const GatherArgs& a, int n_categories, hipStream_t stream) {
     (void)hipGetLastError();
+    if (a.n_leaf == 0 && a.n_src == 0) return hipErrorInvalidValue;
     const int ndev = a.err == nullptr ? 1 : a.n_dev;
-    if ((ndev == 1 || ndev == 3) && a.n_leaf >= 1 && a.n_leaf <= 2) {
+    if ((ndev == 1 || ndev == 3) && a.n_leaf <= 2 && a.n_src <= 2) {
         dim3 grid((a.ld / 2 + 255) / 256, (a.rows_store + kFastRows - 1) / kFastRows, n_categories);
-        if (a.n_leaf == 1) { if (ndev == 1) launch_fast<1, 1>(a, grid, stream); else launch_fast<1, 3>(a, grid, stream); }
+        if (a.n_leaf == 0) launch_fast<0, 1>(a, grid, stream);
+        else if (a.n_leaf == 1) { if (ndev == 1) launch_fast<1, 1>(a, grid, stream); else launch_fast<1, 3>(a, grid, stream); }
         else { if (ndev == 1) launch_fast<2, 1>(a, grid, stream); else launch_fast<2, 3>(a, grid, stream); }
         return hipGetLastError();
     }
     dim3 grid((a.ld + 255) / 256, (a.rows_store + kGatherRows - 1) / kGatherRows, n_categories), block(256);
     hipLaunchKernelGGL(leaf_gather_kernel, grid, block, 0, stream, a);
-    return hipGetLastError();
-}
-
-// Subtree-level de-duplication: families that agree on every leaf under a node share that node's likelihood column,
-// so a child's panel (and the GEMM over it) has one column per DISTINCT pattern below the child; the parent's
-// columns pick theirs up through an index map.  Same arithmetic per column as without the de-duplication.
-__global__ __launch_bounds__(256) void combine_kernel(double* __restrict__ dst, int64_t ld_dst, const double* __restrict__ src, int64_t ld_src,
-                                                      const int32_t* __restrict__ map, int rows, int64_t cols, int64_t kstride, int mode) {
-    const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
-    if (u >= cols) return;
-    const int r0 = blockIdx.y * 8;
-    const int32_t m0 = map[u], m1 = map[u + 1];
-    const double* s = src + (int64_t)blockIdx.z * kstride;
-    double* d = dst + (int64_t)blockIdx.z * kstride + u;
-    double2 v[8];
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-        const int r = r0 + rr;
-        v[rr] = make_double2(0.0, 0.0);
-        if (r < rows) {
-            v[rr].x = s[(int64_t)r * ld_src + m0];
-            v[rr].y = s[(int64_t)r * ld_src + m1];
-            if (mode) {
-                const double2 old = *reinterpret_cast<const double2*>(d + (int64_t)r * ld_dst);
-                v[rr].x *= old.x;
-                v[rr].y *= old.y;
-            }
-        }
-    }
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr)
-        if (r0 + rr < rows) *reinterpret_cast<double2*>(d + (int64_t)(r0 + rr) * ld_dst) = v[rr];
-}
-
-hipError_t launch_combine(double* dst, int64_t ld_dst, const double* src, int64_t ld_src, const int32_t* map, int rows, int64_t cols,
-                          int64_t panel_kstride, int n_categories, int mode, hipStream_t stream) {
-    (void)hipGetLastError();
-    dim3 grid((unsigned)((cols / 2 + 255) / 256), (unsigned)((rows + 7) / 8), (unsigned)n_categories);
-    hipLaunchKernelGGL(combine_kernel, grid, dim3(256), 0, stream, dst, ld_dst, src, ld_src, map, rows, cols, panel_kstride, mode);
     return hipGetLastError();
 }
 
