@@ -145,8 +145,9 @@ int compute_patterns(cafe_ctx* c, const cafe_problem* p, const std::vector<int64
     c->d_edge_map.assign(n, nullptr);
     c->d_leaf_cnt.assign(n, nullptr);
     c->leaf_rank.assign(n, 0);
-    std::vector<std::vector<int32_t>> pid(n);            // [interior node][distinct family] pattern index
-    std::vector<std::vector<int64_t>> rep(n);            // [interior node][pattern] first distinct family showing it
+    // ---- 1. every interior node's own patterns, children first
+    std::vector<std::vector<int32_t>> pid(n);            // [interior node][distinct family] own pattern index
+    std::vector<std::vector<int64_t>> rep(n);            // [interior node][own pattern] first distinct family showing it
     for (int v = 0; v < n; ++v) {
         if (c->leaf_taxon[v] >= 0) continue;
         std::vector<int> inner, leaves;
@@ -157,15 +158,15 @@ int compute_patterns(cafe_ctx* c, const cafe_problem* p, const std::vector<int64
         pid[v].resize(F);
         std::vector<int32_t> key(kw);
         for (int64_t f = 0; f < F; ++f) {
-            size_t k = 0;
-            for (int u : inner) key[k++] = pid[u][f];
-            for (int u : leaves) key[k++] = p->counts[uniq[f] * T + c->leaf_taxon[u]];
-            std::string ks(reinterpret_cast<const char*>(key.data()), sizeof(int32_t) * kw);
             if (v == c->root) {                          // the root keeps one column per family of the context (K4 reads them
                 pid[v][f] = (int32_t)f;                  // by family index), also when identical families were kept apart
                 rep[v].push_back(f);
                 continue;
             }
+            size_t k = 0;
+            for (int u : inner) key[k++] = pid[u][f];
+            for (int u : leaves) key[k++] = p->counts[uniq[f] * T + c->leaf_taxon[u]];
+            std::string ks(reinterpret_cast<const char*>(key.data()), sizeof(int32_t) * kw);
             auto it = seen.find(ks);
             if (it == seen.end()) {
                 it = seen.emplace(std::move(ks), (int32_t)rep[v].size()).first;
@@ -173,25 +174,50 @@ int compute_patterns(cafe_ctx* c, const cafe_problem* p, const std::vector<int64
             }
             pid[v][f] = it->second;
         }
-        const int64_t U = (int64_t)rep[v].size(), Up = round_up64(U, kBN);
+    }
+    // ---- 2. column space of every interior node, parents first: its own patterns, or -- when all the interior
+    // children of a parent have nearly as many patterns as the parent has columns -- the parent's columns, which
+    // makes those edges direct (GEMM epilogue writes the parent's panel, no assemble pass).  A GEMM column costs about
+    // 6.7 times an assembled one (6.0 ms against 0.9 ms per 50 000 columns at the bench shape): inherit when the
+    // extra GEMM columns stay below 15 % of the parent's.
+    std::vector<int> space(n, -1);
+    space[c->root] = c->root;
+    for (int v = n - 1; v >= 0; --v) {
+        if (c->leaf_taxon[v] >= 0) continue;
+        std::vector<int> inner;
+        int n_leaves = 0;
+        for (int u : c->children[v]) { if (c->leaf_taxon[u] < 0) inner.push_back(u); else ++n_leaves; }
+        const double Uv = (double)rep[space[v]].size();
+        double extra = 0;
+        for (int u : inner) extra += 1.0 - (double)rep[u].size() / Uv;
+        const bool inherit = !inner.empty() && n_leaves <= 1 && extra < 0.15;
+        for (int u : inner) space[u] = inherit ? space[v] : u;
+    }
+    // ---- 3. tables
+    for (int v = 0; v < n; ++v) {
+        if (c->leaf_taxon[v] >= 0) continue;
+        std::vector<int> inner, leaves;
+        for (int u : c->children[v]) (c->leaf_taxon[u] < 0 ? inner : leaves).push_back(u);
+        const std::vector<int64_t>& cols = rep[space[v]];                // representative family of every column of v's panel
+        const int64_t U = (int64_t)cols.size(), Up = round_up64(U, kBN);
         c->pat_cols[v] = Up;
         for (size_t l = 0; l < leaves.size(); ++l) c->leaf_rank[leaves[l]] = (int)l;
         if (!leaves.empty()) {
             std::vector<int32_t> tab(leaves.size() * (size_t)Up, 0);
             for (size_t l = 0; l < leaves.size(); ++l)
-                for (int64_t u2 = 0; u2 < U; ++u2) tab[l * Up + u2] = p->counts[uniq[rep[v][u2]] * T + c->leaf_taxon[leaves[l]]];
+                for (int64_t u2 = 0; u2 < U; ++u2) tab[l * Up + u2] = p->counts[uniq[cols[u2]] * T + c->leaf_taxon[leaves[l]]];
             HIP_TRY(c, hipMalloc(&c->d_leaf_cnt[v], tab.size() * sizeof(int32_t)));
             HIP_TRY(c, hipMemcpy(c->d_leaf_cnt[v], tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         }
         for (int u : inner) {
-            const int64_t Uc = (int64_t)rep[u].size();
-            if (Uc == U) { c->edge_identity[u] = 1; continue; }    // first-occurrence numbering on both sides: same order
+            // same space, or own patterns that happen to be as many as the parent's columns (first-occurrence numbering
+            // on both sides: same order): the child's columns ARE the parent's
+            if (space[u] == space[v] || (int64_t)rep[u].size() == U) { c->edge_identity[u] = 1; continue; }
             std::vector<int32_t> map((size_t)Up, 0);
-            for (int64_t u2 = 0; u2 < U; ++u2) map[u2] = pid[u][rep[v][u2]];
+            for (int64_t u2 = 0; u2 < U; ++u2) map[u2] = pid[u][cols[u2]];
             HIP_TRY(c, hipMalloc(&c->d_edge_map[u], map.size() * sizeof(int32_t)));
             HIP_TRY(c, hipMemcpy(c->d_edge_map[u], map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         }
-        for (int u : inner) { std::vector<int32_t>().swap(pid[u]); }   // children are not needed again
     }
     return CAFE_OK;
 }
