@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--lam", type=float, default=0.002)
     ap.add_argument("--alpha", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-shard", default="", help="R/W: rehearsal on one GPU of what rank R of W would run (no collective)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real thing); gloo only to rehearse the N>1 path on a box with fewer GPUs than ranks")
     ap.add_argument("--cpu-matrices", type=int, default=3, help="matrices built by the O(N^3) reference algorithm in the CPU sample")
@@ -112,8 +113,14 @@ def main():
         pr = P.Params(lambdas=np.array([args.lam]), prior=P.prior_uniform(pb.max_root_family_size), multipliers=mult, cat_probs=probs)
     else:
         pr = P.Params(lambdas=np.array([args.lam]), prior=P.prior_uniform(pb.max_root_family_size))
-    lo, hi = P.shard_families(F, world, rank)
-    shard = dataclasses.replace(pb, counts=np.ascontiguousarray(pb.counts[lo:hi]), family_ids=pb.family_ids[lo:hi])
+    # every rank computes the same partition; shards are balanced by distinct subtree patterns (the device's unit of
+    # work), not by family count
+    if args.emulate_shard:
+        er, ew = (int(x) for x in args.emulate_shard.split("/"))
+        mine = P.shard_families_by_pattern_cost(pb, ew)[er]
+    else:
+        mine = P.shard_families_by_pattern_cost(pb, world)[rank]
+    shard = dataclasses.replace(pb, counts=np.ascontiguousarray(pb.counts[mine]), family_ids=[pb.family_ids[i] for i in mine])
     ctx = capi.Context(shard, max_categories=max(1, K), device=device)
 
     buf = torch.zeros(2, dtype=torch.float64, device="cuda")

@@ -351,3 +351,38 @@ def shard_families(n_families: int, world_size: int, rank: int) -> Tuple[int, in
     base, rem = divmod(n_families, world_size)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_families_by_pattern_cost(pb: "Problem", world_size: int) -> List[np.ndarray]:
+    """Family indices of every rank for the multi-GPU path when the device shares likelihood columns between families
+    that agree on a whole subtree (csrc/cafe_ctx.hip, compute_patterns): a shard's work is the number of DISTINCT
+    leaf-count patterns under every interior node, not its number of families.  Families are ordered by total size and
+    then lexicographically, so that look-alikes land on the same rank; a family's cost is the number of interior nodes at
+    which it is the first of its shard-order neighbours to show its pattern, and the ranks get consecutive runs of equal
+    cumulative cost.  Any partition gives the same -lnL (a sum over families); this one balances the ranks."""
+    C = np.ascontiguousarray(pb.counts)
+    F = C.shape[0]
+    if world_size <= 1:
+        return [np.arange(F)]
+    n = pb.n_nodes
+    children: List[List[int]] = [[] for _ in range(n)]
+    for v in range(n):
+        if pb.parent[v] >= 0:
+            children[int(pb.parent[v])].append(v)
+    leafset: List[List[int]] = [[] for _ in range(n)]
+    for v in range(n):                                   # children before parents
+        leafset[v] = [int(pb.leaf_taxon[v])] if pb.leaf_taxon[v] >= 0 else [t for c in children[v] for t in leafset[c]]
+    order = np.lexsort(tuple(C[:, ::-1].T) + (C.sum(axis=1),))
+    Cs = C[order]
+    cost = np.zeros(F, dtype=np.float64)
+    for v in range(n):
+        if pb.leaf_taxon[v] >= 0 or pb.parent[v] < 0:
+            continue
+        cols = np.ascontiguousarray(Cs[:, leafset[v]])
+        _, first = np.unique(cols.view([("", cols.dtype)] * cols.shape[1]), return_index=True)
+        cost[first] += 1.0
+    cum = np.cumsum(cost)
+    bounds = [0] + [int(np.searchsorted(cum, cum[-1] * r / world_size)) for r in range(1, world_size)] + [F]
+    for r in range(1, world_size + 1):                   # never an empty shard
+        bounds[r] = max(bounds[r], bounds[r - 1] + 1) if r < world_size else F
+    return [order[bounds[r]:bounds[r + 1]] for r in range(world_size)]

@@ -108,6 +108,18 @@ def test_shard_families_partitions_exactly():
         assert max(sizes) - min(sizes) <= 1
 
 
+def test_pattern_cost_sharding_is_a_partition():
+    from cafexp_amd import synth
+    pb, _ = synth.make_problem(n_taxa=20, n_families=600, max_count=90)
+    for W in (1, 2, 3, 8):
+        parts = P.shard_families_by_pattern_cost(pb, W)
+        assert len(parts) == W and all(len(p) > 0 for p in parts)
+        allidx = np.sort(np.concatenate(parts))
+        assert np.array_equal(allidx, np.arange(pb.n_families))
+    a, b = P.shard_families_by_pattern_cost(pb, 4), P.shard_families_by_pattern_cost(pb, 4)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))            # every rank derives the same partition
+
+
 def test_synthetic_generator_is_deterministic():
     from cafexp_amd import synth
     a, ta = synth.make_problem(n_taxa=16, n_families=200, max_count=80, seed=5, root_cap=50)
