@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libcafe_mi355x.so")
 
 CAFE_MAX_CATEGORIES = 32
 CAFE_FLAG_NO_DEDUP = 1
+CAFE_FLAG_NO_SUBTREE_DEDUP = 2
 CAFE_MODEL_BASE, CAFE_MODEL_GAMMA = 0, 1
 
 _i32p = C.POINTER(C.c_int32)
@@ -140,7 +141,7 @@ class Context:
     """One cafe_ctx: a family shard resident on one GPU (model state of the reference's scorer)."""
 
     def __init__(self, pb: Problem, max_categories: int = 1, device: int = 0, dedup: bool = True,
-                 workspace_limit: int = 0):
+                 workspace_limit: int = 0, subtree_dedup: bool = True):
         self._lib = load()
         self._keep = []
         k = self._c
@@ -160,7 +161,7 @@ class Context:
         cp.max_categories = max_categories
         cp.n_deviations = pb.n_deviations
         cp.device = device
-        cp.flags = 0 if dedup else CAFE_FLAG_NO_DEDUP
+        cp.flags = (0 if dedup else CAFE_FLAG_NO_DEDUP) | (0 if subtree_dedup else CAFE_FLAG_NO_SUBTREE_DEDUP)
         cp.workspace_limit = workspace_limit
         err = C.create_string_buffer(512)
         self._h = self._lib.cafe_create(C.byref(cp), err, 512)

@@ -269,6 +269,23 @@ def test_dedup_and_weights(capi, oracle):
     assert rel_err(va, oracle.score_base(pb, pr)) <= SCORE_TOL
 
 
+@pytest.mark.parametrize("name", ["mammals_gamma_k4_a2", "mammals_multilambda_err", "synth20_gamma_k8", "synth100_base"])
+def test_subtree_dedup_is_bit_identical(capi, oracle, golden, name):
+    """One panel column per distinct pattern of leaf counts under a node (the default) against one column per family at
+    every node: every column is computed by the same arithmetic, so the per-family values agree to the last bit."""
+    e = golden["scores"][name]
+    pb, pr, alpha = case_from_args(e["args"], oracle)
+    K = 0 if pr.multipliers is None else len(pr.multipliers)
+    a = capi.Context(pb, max_categories=max(1, K))
+    b = capi.Context(pb, max_categories=max(1, K), subtree_dedup=False)
+    va, ra = a.score(pr, alpha=alpha, per_family=True)
+    vb, rb = b.score(pr, alpha=alpha, per_family=True)
+    assert va == vb
+    for key in ra:
+        assert np.array_equal(ra[key], rb[key]), key
+    assert np.array_equal(a.root_max(pr.lambdas), b.root_max(pr.lambdas))
+
+
 def test_chunked_workspace_equals_single_chunk(capi, oracle):
     rng = np.random.default_rng(11)
     pb = _random_problem(rng, "(((A:1,B:1):1,(C:1,D:1):1):1,((E:1,F:1):1,(G:1,H:1):1):1);", 700, 60, 50, 25)
