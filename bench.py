@@ -145,14 +145,14 @@ def main():
     for _ in range(args.warmup):
         value = step()
     fence()
-    flops = ms_gemm = 0.0
+    flops = flops_fam = ms_gemm = 0.0
     launches = 0
     ms_mat = ms_prune = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         value = step()
         st = ctx.stats()                              # HIP events of this call, recorded on the launch stream
-        flops += st["gemm_flops"]; ms_gemm += st["ms_gemm"]; launches += st["gemm_launches"]
+        flops += st["gemm_flops"]; flops_fam += st["gemm_flops_per_family"]; ms_gemm += st["ms_gemm"]; launches += st["gemm_launches"]
         ms_mat += st["ms_matrices"]; ms_prune += st["ms_prune"]
     fence()
     elapsed = time.perf_counter() - t0
@@ -187,7 +187,10 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": "prune_gemm_kernel", "launches_per_step": launches // max(1, args.steps),
-                         "avg_launch_ms": ms_gemm / max(1, launches), "flops_per_launch": flops / max(1, launches)},
+                         "avg_launch_ms": ms_gemm / max(1, launches), "flops_per_launch": flops / max(1, launches),
+                         # columns = distinct subtree patterns: the flops the launches execute; with
+                         # one column per family at every node (SURVEY 8d's per-family figure) they would be:
+                         "flops_per_launch_one_column_per_family": flops_fam / max(1, launches)},
             "phases_ms_per_step": {"bd_matrix_build": ms_mat / args.steps, "prune_total": ms_prune / args.steps,
                                    "prune_gemm": ms_gemm / args.steps},
             "n_matrices": st["n_matrices"],

@@ -51,7 +51,7 @@ class CafeFamilyOut(C.Structure):
 class CafeStats(C.Structure):
     _fields_ = [
         ("ms_total", C.c_double), ("ms_matrices", C.c_double), ("ms_prune", C.c_double), ("ms_gemm", C.c_double),
-        ("ms_reduce", C.c_double), ("gemm_flops", C.c_double), ("gemm_bytes", C.c_double),
+        ("ms_reduce", C.c_double), ("gemm_flops", C.c_double), ("gemm_bytes", C.c_double), ("gemm_flops_per_family", C.c_double),
         ("gemm_launches", C.c_int64), ("n_matrices", C.c_int64), ("n_unique_families", C.c_int64),
         ("n_chunks", C.c_int64), ("matrix_bytes", C.c_int64), ("panel_bytes", C.c_int64),
     ]

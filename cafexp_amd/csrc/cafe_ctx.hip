@@ -560,7 +560,7 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bo
     c->K_last = K;
     c->model_last = rootmax ? CAFE_MODEL_BASE : pr->model;
     c->rootmax_last = rootmax;
-    c->stats.gemm_flops = c->stats.gemm_bytes = 0;
+    c->stats.gemm_flops = c->stats.gemm_bytes = c->stats.gemm_flops_per_family = 0;
     c->stats.gemm_launches = 0;
 
     c->last_rejected = rootmax ? !lambdas_valid(c, pr->lambdas) : rejected(c, pr, K);
@@ -664,6 +664,7 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bo
                 if (c->profile && c->gemm_ev_used + 1 <= c->gemm_ev.size()) HIP_TRY(c, hipEventRecord(c->gemm_ev[c->gemm_ev_used++], s));
                 c->stats.gemm_launches += 1;
                 c->stats.gemm_flops += 2.0 * rows * (c->M + 1) * (double)gc * K;
+                c->stats.gemm_flops_per_family += 2.0 * rows * (c->M + 1) * (double)cols * K;
                 c->stats.gemm_bytes += 8.0 * K * ((double)rows * (c->M + 1) + (double)(c->M + 1) * gc + (double)rows * gc);
             }
         }

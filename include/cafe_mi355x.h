@@ -115,8 +115,11 @@ typedef struct cafe_stats {
     double ms_prune;                 /* K2 prune_gemm + K3 leaf_gather over all nodes */
     double ms_gemm;                  /* K2 only */
     double ms_reduce;                /* K4 root_reduce */
-    double gemm_flops;               /* algorithmic flops: sum over launches of 2*rows*(M+1)*columns */
+    double gemm_flops;               /* algorithmic flops: sum over launches of 2*rows*(M+1)*columns, columns = the
+                                        distinct subtree patterns the launch processes */
     double gemm_bytes;               /* algorithmic bytes of the same launches (P + B read, C written) */
+    double gemm_flops_per_family;    /* the same sum with one column per (distinct) family at every node: SURVEY 8d's
+                                        per-family figure, what the launches would compute without the sharing */
     int64_t gemm_launches;
     int64_t n_matrices;              /* distinct (lambda_q, t_q) keys built */
     int64_t n_unique_families;
