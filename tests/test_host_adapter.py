@@ -14,7 +14,8 @@ DATA = os.path.join(ROOT, "tests", "golden", "data")
 
 
 def test_host_unit_tests_pass():
-    subprocess.check_call(["make", "-s", "-C", HOST, "host_tests"])
+    mk = subprocess.run(["make", "-s", "-C", HOST, "host_tests"], capture_output=True, text=True)
+    assert mk.returncode == 0, mk.stdout + mk.stderr
     out = subprocess.run([os.path.join(HOST, "host_tests")], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "0 failures" in out.stdout
