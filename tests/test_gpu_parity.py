@@ -339,6 +339,11 @@ def test_config4_shape_properties(capi, oracle):
         shard = dataclasses.replace(pb, counts=pb.counts[lo:hi].copy(), family_ids=pb.family_ids[lo:hi])
         parts += capi.Context(shard, max_categories=8).score(pr, alpha=2.0)
     assert rel_err(parts, whole) <= 1e-12
+    parts = 0.0                                           # the shards bench.py uses: balanced by distinct subtree patterns
+    for idx in P.shard_families_by_pattern_cost(pb, 4):
+        shard = dataclasses.replace(pb, counts=np.ascontiguousarray(pb.counts[idx]), family_ids=[pb.family_ids[i] for i in idx])
+        parts += capi.Context(shard, max_categories=8).score(pr, alpha=2.0)
+    assert rel_err(parts, whole) <= 1e-12
     assert rel_err(-np.sum(np.log(res["family_likelihood"])), whole) <= 1e-12
     perm = np.random.default_rng(1).permutation(pb.n_families)
     shuffled = dataclasses.replace(pb, counts=pb.counts[perm].copy())
