@@ -64,7 +64,7 @@ EXPORTS = [
     "cafe_abi_version", "cafe_create", "cafe_destroy", "cafe_last_error", "cafe_score", "cafe_score_partial",
     "cafe_finish_partial", "cafe_family_results", "cafe_get_matrix", "cafe_get_root_likelihoods", "cafe_get_stats",
     "cafe_matrix_size", "cafe_build_matrices", "cafe_probe_fp64_mfma", "cafe_set_profiling", "cafe_debug_stamps",
-    "cafe_root_max", "cafe_reconstruct", "cafe_branch_probabilities", "cafe_pvalues",
+    "cafe_root_max", "cafe_reconstruct", "cafe_branch_probabilities", "cafe_pvalues", "cafe_debug_force_tile",
 ]
 
 _lib = None
@@ -127,6 +127,8 @@ def load():
     L.cafe_probe_fp64_mfma.argtypes = [C.c_int32, _f64p]
     L.cafe_debug_stamps.restype = C.c_int
     L.cafe_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t]
+    L.cafe_debug_force_tile.restype = C.c_int
+    L.cafe_debug_force_tile.argtypes = [C.c_void_p, C.c_int]
     L.cafe_set_profiling.restype = C.c_int
     L.cafe_set_profiling.argtypes = [C.c_void_p, C.c_int]
     _lib = L
@@ -325,6 +327,10 @@ class Context:
         out = np.zeros(words, dtype=np.uint64)
         self._check(self._lib.cafe_debug_stamps(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), words))
         return out
+
+    def force_tile(self, mi: int):
+        """Diagnostic: K2 row tile of 16*mi rows for every launch (0: chosen per launch)."""
+        self._check(self._lib.cafe_debug_force_tile(self._h, mi))
 
     def set_profiling(self, on: bool):
         self._check(self._lib.cafe_set_profiling(self._h, 1 if on else 0))

@@ -96,6 +96,7 @@ struct cafe_ctx {
 
     // measurement
     int profile = 1;
+    int force_mi = 0;                        // diagnostic: K2 row-tile height for every launch (0 = chosen per launch)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> gemm_ev;
     size_t gemm_ev_used = 0;

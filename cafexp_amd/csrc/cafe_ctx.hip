@@ -646,8 +646,8 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bo
                 g.rows = op.to_root ? c->R : c->M;           // parent sizes 1..rows
                 g.out_off = op.to_root ? 0 : 1;
                 g.mode = op.mode;
-                g.mi = prune_gemm_pick_mi(g.rows);
-                g.n_row_tiles = (g.rows + 16 * g.mi - 1) / (16 * g.mi);
+                g.mi = c->force_mi;                         // 0: launch_prune_gemm picks the tile height for this launch
+                g.n_row_tiles = g.mi ? (g.rows + 16 * g.mi - 1) / (16 * g.mi) : 0;
                 g.n_col_tiles = (int)(gc / kBN);
                 { const char* sl = std::getenv("CAFE_GEMM_STAMPS_LAUNCH"); const long want = sl ? std::atol(sl) : -1;
                   g.stamps = (want < 0 || want == (long)c->stats.gemm_launches) ? c->d_stamps : nullptr; }
@@ -898,6 +898,12 @@ int cafe_debug_stamps(cafe_ctx* ctx, unsigned long long* out, size_t words) {
     if (!ctx || !ctx->d_stamps || !out) return CAFE_ERR_STATE;
     if (words > ctx->stamps_words) words = ctx->stamps_words;
     return hipMemcpy(out, ctx->d_stamps, words * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? CAFE_OK : CAFE_ERR_DEVICE;
+}
+
+int cafe_debug_force_tile(cafe_ctx* ctx, int mi) {
+    if (!ctx || (mi != 0 && (mi < 4 || mi > 9))) return CAFE_ERR_ARGUMENT;
+    ctx->force_mi = mi;
+    return CAFE_OK;
 }
 
 int cafe_set_profiling(cafe_ctx* ctx, int on) {

@@ -123,7 +123,7 @@ hipError_t launch_bd_matrix_build(const MatrixPool& pool, const SlotParam* d_slo
 hipError_t launch_bd_matrix_build_both(const MatrixPool& pool, const MatrixPool& kpool, const SlotParam* d_slots, const SlotParam* d_kslots,
                                        int n_slots, int n_kslots, hipStream_t stream);
 hipError_t launch_prune_gemm(const GemmArgs& a, int n_categories, hipStream_t stream);
-int prune_gemm_pick_mi(int rows);     // row-tile height (in 16-row blocks) with the least padding
+int prune_gemm_pick_mi(int rows, int n_col_tiles, int n_categories, int slots);     // row-tile height (in 16-row blocks)
 hipError_t launch_leaf_gather(const GatherArgs& a, int n_categories, hipStream_t stream);
 hipError_t launch_root_reduce(const ReduceArgs& a, hipStream_t stream);
 // sum_f w_f * fam_out[f] and the number of failed families -> out[0], out[1]

@@ -188,6 +188,8 @@ int cafe_get_stats(const cafe_ctx* ctx, cafe_stats* stats);
 int cafe_matrix_size(const cafe_ctx* ctx);
 /* 1 (default): bracket every K2 launch with HIP events so that cafe_stats.ms_gemm is measured; 0: off. */
 int cafe_set_profiling(cafe_ctx* ctx, int on);
+/* diagnostic: K2's row tile is 16*mi rows, mi = 4..9, normally chosen per launch; mi forces one, 0 restores the choice */
+int cafe_debug_force_tile(cafe_ctx* ctx, int mi);
 /* diagnostic (CAFE_GEMM_STAMPS=1 at cafe_create): per-block placement + timeline words of the last K2 launch */
 int cafe_debug_stamps(cafe_ctx* ctx, unsigned long long* out, size_t words);
 
