@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from cafexp_amd import problem as P, capi, synth
 from cafexp_amd.gamma_rates import discrete_gamma
