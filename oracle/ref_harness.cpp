@@ -23,6 +23,12 @@
 //             [nsim= seed= pvalue=0.05 files=1]   the tail of estimator::execute (execute.cpp:147-180): infer once,
 //             [compute_pvalues,] reconstruct_ancestral_states, compute_viterbi_sum for every family and node;
 //             files=1 adds the text of every report reconstruction::write_results writes
+//   search    tree= families= [model=gamma k= [alpha=]] [lambda_tree=] [errfile=|estimate_error=1] [prior=] [limit=] [seed=10]
+//             estimator::estimate_missing_variables (execute.cpp:82-105): model::get_lambda_optimizer + the reference's
+//             optimizer (Nelder-Mead, optimizer.cpp:539) at a fixed seed of the global engine
+//   Every job that builds a model (score, reconstruct, search) takes device=hip when this file is compiled with
+//   -DCAFE_HIP_BINDING (oracle/_ref/ref_hip_harness): the model is then integration/hip_models.h's hip_base_model /
+//   hip_gamma_model -- the reference's own classes, optimizer and writers running on the MI355X library.
 //   cafexp    <the reference program's own command line>   runs cafexp() (src/cafexp.cpp:175) unchanged, e.g.
 //             ref_harness cafexp -t tree -i families -k 3 -o /tmp/out ; prints {"rc": .., "seconds": ..}
 //   pvalues   tree= families= lambda=|lambdas= lambda_tree= [nsim=1000] [seed=10] [ncond=0] [limit=] [m= r=]
@@ -45,8 +51,12 @@
 #include "src/io.h"
 #include "src/core.h"
 #include "src/user_data.h"
+#ifdef CAFE_HIP_BINDING
+#include "hip_models.h"          // includes base_model.h and gamma_core.h (the latter has no include guard)
+#else
 #include "src/base_model.h"
 #include "src/gamma_core.h"
+#endif
 #include "src/gamma.h"
 #include "src/matrix_cache.h"
 #include "src/probability.h"
@@ -56,6 +66,8 @@
 #include "src/error_model.h"
 #include "src/gene_family.h"
 #include "src/gene_family_reconstructor.h"
+#include "src/optimizer.h"
+#include "src/optimizer_scorer.h"
 
 std::mt19937 randomizer_engine(10);   // main.cpp:3 / test.cpp:35 define this global
 int cafexp(int argc, char* const argv[]);   // src/cafexp.cpp:175
@@ -95,6 +107,27 @@ static void parr(const char* name, const std::vector<double>& v) {
 }
 static double now() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// base_model / gamma_model as build_models (core.cpp:16-50) would construct them; device=hip: the binding's classes
+static model* make_model(const kv_t& kv, user_data& d) {
+    const std::string mdl = gets(kv, "model", "base");
+    const bool hip = gets(kv, "device", "cpu") == "hip";
+#ifndef CAFE_HIP_BINDING
+    if (hip) throw std::runtime_error("device=hip needs the ref_hip_harness build (-DCAFE_HIP_BINDING)");
+#endif
+    if (mdl == "gamma") {
+#ifdef CAFE_HIP_BINDING
+        if (hip) return new hip_gamma_model(d.p_lambda, d.p_tree, &d.gene_families, d.max_family_size, d.max_root_family_size,
+                                            geti(kv, "k"), getd(kv, "alpha"), d.p_error_model);
+#endif
+        return new gamma_model(d.p_lambda, d.p_tree, &d.gene_families, d.max_family_size, d.max_root_family_size,
+                               geti(kv, "k"), getd(kv, "alpha"), d.p_error_model);
+    }
+#ifdef CAFE_HIP_BINDING
+    if (hip) return new hip_base_model(d.p_lambda, d.p_tree, &d.gene_families, d.max_family_size, d.max_root_family_size, d.p_error_model);
+#endif
+    return new base_model(d.p_lambda, d.p_tree, &d.gene_families, d.max_family_size, d.max_root_family_size, d.p_error_model);
 }
 
 static int job_bd(const kv_t& kv) {
@@ -186,16 +219,9 @@ static int job_score(const kv_t& kv) {
     else prior.reset(new ::poisson_distribution(std::stod(pr.substr(pr.find(':') + 1))));
 
     std::string mdl = gets(kv, "model", "base");
-    std::unique_ptr<model> m;
+    std::unique_ptr<model> m(make_model(kv, d));
     std::vector<double> mults;
-    if (mdl == "gamma") {
-        auto g = new gamma_model(d.p_lambda, d.p_tree, &d.gene_families, d.max_family_size, d.max_root_family_size,
-            geti(kv, "k"), getd(kv, "alpha"), d.p_error_model);
-        mults = g->get_lambda_multipliers();
-        m.reset(g);
-    } else {
-        m.reset(new base_model(d.p_lambda, d.p_tree, &d.gene_families, d.max_family_size, d.max_root_family_size, d.p_error_model));
-    }
+    if (auto g = dynamic_cast<gamma_model*>(m.get())) mults = g->get_lambda_multipliers();
     int reps = geti(kv, "reps", 1);
     double score = 0, best = 1e300;
     for (int r = 0; r < reps; ++r) {
@@ -319,12 +345,7 @@ static int job_reconstruct(const kv_t& kv) {
     std::string prs = gets(kv, "prior", "uniform");
     if (prs == "uniform") prior.reset(new uniform_distribution());
     else prior.reset(new ::poisson_distribution(std::stod(prs.substr(prs.find(':') + 1))));
-    std::string mdl = gets(kv, "model", "base");
-    std::unique_ptr<model> m;
-    if (mdl == "gamma")
-        m.reset(new gamma_model(d.p_lambda, d.p_tree, &d.gene_families, d.max_family_size, d.max_root_family_size, geti(kv, "k"), getd(kv, "alpha"), d.p_error_model));
-    else
-        m.reset(new base_model(d.p_lambda, d.p_tree, &d.gene_families, d.max_family_size, d.max_root_family_size, d.p_error_model));
+    std::unique_ptr<model> m(make_model(kv, d));
     const double test_pvalue = getd(kv, "pvalue", 0.05);
     const int nsim = geti(kv, "nsim", 0);
 
@@ -343,7 +364,12 @@ static int job_reconstruct(const kv_t& kv) {
     cladevector order;
     d.p_tree->apply_reverse_level_order([&order](const clade* c) { order.push_back(c); });
     branch_probabilities probs;                                                              // execute.cpp:165-176
-    for (size_t i = 0; i < d.gene_families.size(); ++i)
+    bool probs_done = false;
+#ifdef CAFE_HIP_BINDING
+    if (auto hb = dynamic_cast<hip_base_model*>(m.get())) { probs = hip_compute_branch_probabilities(hb, hb->device_context(), rec.get(), d.gene_families, pvalues, test_pvalue); probs_done = true; }
+    if (auto hg = dynamic_cast<hip_gamma_model*>(m.get())) { probs = hip_compute_branch_probabilities(hg, hg->device_context(), rec.get(), d.gene_families, pvalues, test_pvalue); probs_done = true; }
+#endif
+    for (size_t i = 0; !probs_done && i < d.gene_families.size(); ++i)
         if (pvalues[i] < test_pvalue)
             for (auto c : order) probs.set(d.gene_families[i], c, compute_viterbi_sum(c, d.gene_families[i], rec.get(), d.max_family_size, cache, m->get_lambda()));
 
@@ -407,6 +433,57 @@ static int job_reconstruct(const kv_t& kv) {
     return 0;
 }
 
+static int job_search(const kv_t& kv) {
+    input_parameters p;
+    p.tree_file_path = gets(kv, "tree");
+    p.input_file_path = gets(kv, "families");
+    if (has(kv, "lambda_tree")) p.lambda_tree_file_path = gets(kv, "lambda_tree");
+    if (has(kv, "errfile")) { p.use_error_model = true; p.error_model_file_path = gets(kv, "errfile"); }
+    if (has(kv, "lambda")) p.fixed_lambda = getd(kv, "lambda");          // with model=gamma and no alpha: estimate alpha only
+    user_data d;
+    d.read_datafiles(p);
+    if (geti(kv, "rootfilter", 1)) {
+        auto rem = std::remove_if(d.gene_families.begin(), d.gene_families.end(), [&](const gene_family& fam) {
+            return !fam.exists_at_root(d.p_tree); });
+        d.gene_families.erase(rem, d.gene_families.end());
+    }
+    if (has(kv, "limit")) {
+        size_t lim = (size_t)geti(kv, "limit");
+        if (d.gene_families.size() > lim) d.gene_families.resize(lim);
+    }
+    if (has(kv, "m")) d.max_family_size = geti(kv, "m");
+    if (has(kv, "r")) d.max_root_family_size = geti(kv, "r");
+    std::string prs = gets(kv, "prior", "uniform");
+    if (prs == "uniform") d.p_prior.reset(new uniform_distribution());
+    else d.p_prior.reset(new ::poisson_distribution(std::stod(prs.substr(prs.find(':') + 1))));
+    std::unique_ptr<error_model> default_em;
+    const bool estimate_error = geti(kv, "estimate_error", 0) != 0;
+    error_model* user_em = d.p_error_model;
+    if (estimate_error) {                       // build_models' default error model when -e has no file (core.cpp:39-44)
+        default_em.reset(new error_model());
+        default_em->set_probabilities(0, { 0, .95, 0.05 });
+        default_em->set_probabilities(d.max_family_size, { 0.05, .9, 0.05 });
+        d.p_error_model = default_em.get();
+    }
+    std::unique_ptr<model> m(make_model(kv, d));
+    d.p_error_model = estimate_error ? nullptr : user_em;   // user_data keeps "no error model given" (base_model.cpp:133)
+    randomizer_engine.seed(geti(kv, "seed", 10));
+    std::unique_ptr<inference_optimizer_scorer> scorer(m->get_lambda_optimizer(d));
+    if (!scorer) { printf("{\"error\": \"nothing to optimise\"}\n"); return 1; }
+    optimizer opt(scorer.get());
+    opt.quiet = true;
+    optimizer_parameters params;
+    double t0 = now();
+    auto result = opt.optimize(params);
+    double dt = now() - t0;
+    scorer->finalize(&result.values[0]);
+    printf("{\"score\": "); pd(result.score);
+    printf(", \"iterations\": %d, \"seconds\": %.6f, \"threads\": %d, \"n_families\": %zu, ", result.num_iterations, dt, omp_get_max_threads(), d.gene_families.size());
+    parr("values", result.values);
+    printf("}\n");
+    return 0;
+}
+
 static int job_time_matrices(const kv_t& kv) {
     int n = geti(kv, "n"), count = geti(kv, "count", 1);
     double lambda = getd(kv, "lambda"), t0v = getd(kv, "t0", 1.0);
@@ -444,6 +521,7 @@ int main(int argc, char** argv) {
         if (job == "time_matrices") return job_time_matrices(kv);
         if (job == "pvalues") return job_pvalues(kv);
         if (job == "reconstruct") return job_reconstruct(kv);
+        if (job == "search") return job_search(kv);
     } catch (std::exception& e) {
         fprintf(stderr, "ref_harness: %s\n", e.what());
         return 1;
