@@ -65,7 +65,11 @@ EXPORTS = [
     "cafe_finish_partial", "cafe_family_results", "cafe_get_matrix", "cafe_get_root_likelihoods", "cafe_get_stats",
     "cafe_matrix_size", "cafe_build_matrices", "cafe_probe_fp64_mfma", "cafe_set_profiling", "cafe_debug_stamps",
     "cafe_root_max", "cafe_reconstruct", "cafe_branch_probabilities", "cafe_pvalues", "cafe_debug_force_tile",
+    "cafe_comm_unique_id", "cafe_comm_attach", "cafe_comm_detach", "cafe_shard_plan", "cafe_create_sharded",
+    "cafe_sharded_destroy", "cafe_sharded_last_error", "cafe_sharded_score", "cafe_sharded_family_results",
+    "cafe_sharded_size", "cafe_sharded_context",
 ]
+CAFE_COMM_ID_BYTES = 128
 
 _lib = None
 
@@ -131,12 +135,103 @@ def load():
     L.cafe_debug_force_tile.argtypes = [C.c_void_p, C.c_int]
     L.cafe_set_profiling.restype = C.c_int
     L.cafe_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.cafe_comm_unique_id.restype = C.c_int
+    L.cafe_comm_unique_id.argtypes = [C.c_char_p]
+    L.cafe_comm_attach.restype = C.c_int
+    L.cafe_comm_attach.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32]
+    L.cafe_comm_detach.restype = C.c_int
+    L.cafe_comm_detach.argtypes = [C.c_void_p]
+    L.cafe_shard_plan.restype = C.c_int
+    L.cafe_shard_plan.argtypes = [C.POINTER(CafeProblem), C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.cafe_create_sharded.restype = C.c_void_p
+    L.cafe_create_sharded.argtypes = [C.POINTER(CafeProblem), _i32p, C.c_int32, C.c_char_p, C.c_size_t]
+    L.cafe_sharded_destroy.restype = None
+    L.cafe_sharded_destroy.argtypes = [C.c_void_p]
+    L.cafe_sharded_last_error.restype = C.c_char_p
+    L.cafe_sharded_last_error.argtypes = [C.c_void_p]
+    L.cafe_sharded_score.restype = C.c_int
+    L.cafe_sharded_score.argtypes = [C.c_void_p, C.POINTER(CafeParams), _f64p, C.POINTER(CafeFamilyOut)]
+    L.cafe_sharded_family_results.restype = C.c_int
+    L.cafe_sharded_family_results.argtypes = [C.c_void_p, C.POINTER(CafeFamilyOut)]
+    L.cafe_sharded_size.restype = C.c_int32
+    L.cafe_sharded_size.argtypes = [C.c_void_p]
+    L.cafe_sharded_context.restype = C.c_void_p
+    L.cafe_sharded_context.argtypes = [C.c_void_p, C.c_int32]
     _lib = L
     return L
 
 
 def _p(a, t):
     return a.ctypes.data_as(t) if a is not None else None
+
+
+def _c_problem(pb: Problem, keep: list, max_categories: int = 1, device: int = 0, flags: int = 0, workspace_limit: int = 0) -> CafeProblem:
+    def k(a, dt):
+        a = np.ascontiguousarray(a, dtype=dt)
+        keep.append(a)
+        return a
+    cp = CafeProblem()
+    cp.n_nodes = pb.n_nodes
+    cp.parent = _p(k(pb.parent, np.int32), _i32p)
+    cp.branch_length = _p(k(pb.branch_length, np.float64), _f64p)
+    cp.lambda_index = _p(k(pb.lambda_index, np.int32), _i32p)
+    cp.leaf_taxon = _p(k(pb.leaf_taxon, np.int32), _i32p)
+    cp.n_taxa = pb.n_taxa
+    cp.n_families = pb.n_families
+    cp.counts = _p(k(pb.counts, np.int32), _i32p)
+    cp.max_family_size = pb.max_family_size
+    cp.max_root_family_size = pb.max_root_family_size
+    cp.n_lambdas = pb.n_lambdas
+    cp.single_lambda = 1 if pb.single_lambda else 0
+    cp.max_categories = max_categories
+    cp.n_deviations = pb.n_deviations
+    cp.device = device
+    cp.flags = flags
+    cp.workspace_limit = workspace_limit
+    return cp
+
+
+def _c_params(pr: Params, alpha: float = 1.0):
+    keep = []
+
+    def k(a, dt):
+        a = np.ascontiguousarray(a, dtype=dt)
+        keep.append(a)
+        return a
+    cp = CafeParams()
+    cp.model = CAFE_MODEL_GAMMA if pr.multipliers is not None else CAFE_MODEL_BASE
+    cp.lambdas = _p(k(pr.lambdas, np.float64), _f64p)
+    if pr.multipliers is not None:
+        cp.n_categories = len(pr.multipliers)
+        cp.multipliers = _p(k(pr.multipliers, np.float64), _f64p)
+        cp.cat_probs = _p(k(pr.cat_probs, np.float64), _f64p)
+    else:
+        cp.n_categories = 1
+    cp.alpha = alpha
+    cp.prior = _p(k(pr.prior, np.float32), _f32p)
+    cp.error_model = _p(k(pr.error_model, np.float64), _f64p) if pr.error_model is not None else None
+    return cp, keep
+
+
+def shard_plan(pb: Problem, n_shards: int):
+    """cafe_shard_plan: the library's balanced family partition (host code, no GPU needed).
+    Returns the family indices of every shard (a list of n_shards int64 arrays)."""
+    keep = []
+    cp = _c_problem(pb, keep)
+    order = np.empty(pb.n_families, dtype=np.int64)
+    bounds = np.empty(n_shards + 1, dtype=np.int64)
+    rc = load().cafe_shard_plan(C.byref(cp), n_shards, order.ctypes.data_as(C.POINTER(C.c_int64)), bounds.ctypes.data_as(C.POINTER(C.c_int64)))
+    if rc:
+        raise CafeError("cafe_shard_plan failed with code %d" % rc)
+    return [order[bounds[r]:bounds[r + 1]].copy() for r in range(n_shards)]
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(CAFE_COMM_ID_BYTES)
+    rc = load().cafe_comm_unique_id(buf)
+    if rc:
+        raise CafeError("cafe_comm_unique_id failed with code %d" % rc)
+    return buf.raw
 
 
 class Context:
@@ -146,25 +241,8 @@ class Context:
                  workspace_limit: int = 0, subtree_dedup: bool = True):
         self._lib = load()
         self._keep = []
-        k = self._c
-        cp = CafeProblem()
-        cp.n_nodes = pb.n_nodes
-        cp.parent = _p(k(pb.parent, np.int32), _i32p)
-        cp.branch_length = _p(k(pb.branch_length, np.float64), _f64p)
-        cp.lambda_index = _p(k(pb.lambda_index, np.int32), _i32p)
-        cp.leaf_taxon = _p(k(pb.leaf_taxon, np.int32), _i32p)
-        cp.n_taxa = pb.n_taxa
-        cp.n_families = pb.n_families
-        cp.counts = _p(k(pb.counts, np.int32), _i32p)
-        cp.max_family_size = pb.max_family_size
-        cp.max_root_family_size = pb.max_root_family_size
-        cp.n_lambdas = pb.n_lambdas
-        cp.single_lambda = 1 if pb.single_lambda else 0
-        cp.max_categories = max_categories
-        cp.n_deviations = pb.n_deviations
-        cp.device = device
-        cp.flags = (0 if dedup else CAFE_FLAG_NO_DEDUP) | (0 if subtree_dedup else CAFE_FLAG_NO_SUBTREE_DEDUP)
-        cp.workspace_limit = workspace_limit
+        cp = _c_problem(pb, self._keep, max_categories, device,
+                        (0 if dedup else CAFE_FLAG_NO_DEDUP) | (0 if subtree_dedup else CAFE_FLAG_NO_SUBTREE_DEDUP), workspace_limit)
         err = C.create_string_buffer(512)
         self._h = self._lib.cafe_create(C.byref(cp), err, 512)
         if not self._h:
@@ -175,11 +253,6 @@ class Context:
         self.n_nodes = pb.n_nodes
         self.n_families = pb.n_families
         self._keep = []          # cafe_create copied everything
-
-    def _c(self, a, dt):
-        a = np.ascontiguousarray(a, dtype=dt)
-        self._keep.append(a)
-        return a
 
     def close(self):
         if getattr(self, "_h", None):
@@ -197,25 +270,15 @@ class Context:
             raise CafeError("code %d: %s" % (rc, self._lib.cafe_last_error(self._h).decode()))
 
     def _params(self, pr: Params, alpha: float = 1.0):
-        keep = []
+        return _c_params(pr, alpha)
 
-        def k(a, dt):
-            a = np.ascontiguousarray(a, dtype=dt)
-            keep.append(a)
-            return a
-        cp = CafeParams()
-        cp.model = CAFE_MODEL_GAMMA if pr.multipliers is not None else CAFE_MODEL_BASE
-        cp.lambdas = _p(k(pr.lambdas, np.float64), _f64p)
-        if pr.multipliers is not None:
-            cp.n_categories = len(pr.multipliers)
-            cp.multipliers = _p(k(pr.multipliers, np.float64), _f64p)
-            cp.cat_probs = _p(k(pr.cat_probs, np.float64), _f64p)
-        else:
-            cp.n_categories = 1
-        cp.alpha = alpha
-        cp.prior = _p(k(pr.prior, np.float32), _f32p)
-        cp.error_model = _p(k(pr.error_model, np.float64), _f64p) if pr.error_model is not None else None
-        return cp, keep
+    def comm_attach(self, comm_id: bytes, world_size: int, rank: int):
+        """Join the RCCL communicator of the ranks holding the other family shards: from now on score() all-reduces
+        {sum lnL, rejects} and returns the whole table's value on every rank (collective call)."""
+        self._check(self._lib.cafe_comm_attach(self._h, comm_id, world_size, rank))
+
+    def comm_detach(self):
+        self._check(self._lib.cafe_comm_detach(self._h))
 
     def score(self, pr: Params, alpha: float = 1.0, per_family: bool = False):
         """One infer_family_likelihoods call -> -lnL (float, may be inf / nan)."""
@@ -334,6 +397,76 @@ class Context:
 
     def set_profiling(self, on: bool):
         self._check(self._lib.cafe_set_profiling(self._h, 1 if on else 0))
+
+
+class _Borrowed(Context):
+    """A shard's cafe_ctx owned by a Sharded object: statistics and introspection only."""
+
+    def __init__(self, lib, handle, n_families):
+        self._lib, self._h, self.n_families = lib, handle, n_families
+
+    def close(self):
+        self._h = None
+
+
+class Sharded:
+    """cafe_create_sharded: one process, several GPUs -- family shards, one host thread and stream per device, one
+    RCCL all-reduce per scorer call."""
+
+    def __init__(self, pb: Problem, devices, max_categories: int = 1, dedup: bool = True, subtree_dedup: bool = True):
+        self._lib = load()
+        keep = []
+        cp = _c_problem(pb, keep, max_categories, 0, (0 if dedup else CAFE_FLAG_NO_DEDUP) | (0 if subtree_dedup else CAFE_FLAG_NO_SUBTREE_DEDUP))
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        err = C.create_string_buffer(512)
+        self._h = self._lib.cafe_create_sharded(C.byref(cp), _p(dev, _i32p), len(dev), err, 512)
+        if not self._h:
+            raise CafeError(err.value.decode() or "cafe_create_sharded failed")
+        self.n_families = pb.n_families
+        self.size = self._lib.cafe_sharded_size(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cafe_sharded_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise CafeError("code %d: %s" % (rc, self._lib.cafe_sharded_last_error(self._h).decode()))
+
+    def score(self, pr: Params, alpha: float = 1.0, per_family: bool = False):
+        cp, keep = _c_params(pr, alpha)
+        out = C.c_double()
+        self._check(self._lib.cafe_sharded_score(self._h, C.byref(cp), C.byref(out), None))
+        if not per_family:
+            return out.value
+        return out.value, self.family_results(len(pr.multipliers) if pr.multipliers is not None else 0)
+
+    def family_results(self, K: int = 0):
+        F = self.n_families
+        fo = CafeFamilyOut()
+        res = {"family_lnl": np.empty(F), "failed": np.empty(F, dtype=np.int32)}
+        fo.family_lnl = _p(res["family_lnl"], _f64p)
+        fo.failed = _p(res["failed"], _i32p)
+        if K > 0:
+            res["category_likelihood"] = np.empty((F, K))
+            res["family_likelihood"] = np.empty(F)
+            fo.category_likelihood = _p(res["category_likelihood"], _f64p)
+            fo.family_likelihood = _p(res["family_likelihood"], _f64p)
+        self._check(self._lib.cafe_sharded_family_results(self._h, C.byref(fo)))
+        return res
+
+    def shard(self, r: int) -> Context:
+        h = self._lib.cafe_sharded_context(self._h, r)
+        if not h:
+            raise CafeError("no shard %d" % r)
+        return _Borrowed(self._lib, h, 0)
 
 
 def build_matrices(n: int, lambdas, ts, device: int = 0, layout: int = 0) -> np.ndarray:

@@ -87,6 +87,12 @@ struct cafe_ctx {
     hipEvent_t ev_upload = nullptr;
     bool upload_pending = false;
 
+    // multi-GPU: an RCCL communicator over the ranks that hold the other family shards (cafe_sharded.hip); with one
+    // attached, cafe_score all-reduces {sum lnL, rejects} before the read-back
+    void* comm = nullptr;                    // ncclComm_t
+    bool comm_owned = false;
+    int comm_world = 1, comm_rank = 0;
+
     // last call
     std::vector<int> slot_of;               // [node*Kmax + k]
     int K_last = 0, model_last = -1;
@@ -133,5 +139,8 @@ int pvalues_impl(cafe_ctx* c, const cafe_params* pr, int32_t n_simulations, uint
 cafe_ctx* create_child_for_device_counts(const cafe_ctx* parent, int64_t n_families);
 void destroy_child(cafe_ctx* c);
 int enqueue_rootmax(cafe_ctx* c, const double* lambdas, hipStream_t s);
+// multi-GPU (cafe_sharded.hip)
+int comm_allreduce_pair(cafe_ctx* c, double* d_pair, hipStream_t s);
+void comm_release(cafe_ctx* c);
 
 }  // namespace cafe

@@ -232,6 +232,7 @@ void free_device(cafe_ctx* c) {
     if (!c->device_ready) return;            // nothing was created on a device (argument / device errors)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    comm_release(c);
     hipFree(c->d_counts); hipFree(c->d_weights); hipFree(c->pool.base); hipFree(c->kpool.base); hipFree(c->d_slots); hipFree(c->d_panels);
     hipFree(c->d_prior); hipFree(c->d_logprior); hipFree(c->d_catprobs); hipFree(c->d_err);
     hipFree(c->d_fam_out); hipFree(c->d_fam_lik); hipFree(c->d_cat_out); hipFree(c->d_failed);
@@ -792,6 +793,8 @@ int cafe_score(cafe_ctx* ctx, const cafe_params* params, double* neg_lnl, const 
         set_err(ctx, "cafe_score: %s", e.what());
         return CAFE_ERR_MEMORY;
     }
+    if (rc != CAFE_OK) return rc;
+    rc = comm_allreduce_pair(ctx, ctx->d_result, ctx->stream);          // family shards on other GPUs: one RCCL all-reduce
     if (rc != CAFE_OK) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -1,0 +1,410 @@
+// Multi-GPU scorer behind the C ABI (include/cafe_mi355x.h, "Multi-GPU").
+//
+// The reference parallelises one scorer call with OpenMP over families (base_model.cpp:81-107,
+// gamma_core.cpp:201-244); its only cross-family operations are the final sum (base_model.cpp:107,
+// gamma_core.cpp:244) and the any-failure test (gamma_core.cpp:227).  Here families shard across the GPUs of a node,
+// every GPU builds all transition matrices itself, and ONE RCCL all-reduce over xGMI of {sum lnL, rejects} closes
+// the call.  Host code only: the shard plan, the communicator plumbing and one host thread per device.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "cafe_ctx.h"
+
+static_assert(CAFE_COMM_ID_BYTES >= sizeof(ncclUniqueId), "CAFE_COMM_ID_BYTES must hold an ncclUniqueId");
+
+namespace cafe {
+
+// {sum lnL, rejects} summed over the communicator's ranks, in place, on the stream the call was enqueued on
+int comm_allreduce_pair(cafe_ctx* c, double* d_pair, hipStream_t s) {
+    if (!c->comm) return CAFE_OK;
+    const ncclResult_t r = ncclAllReduce(d_pair, d_pair, 2, ncclDouble, ncclSum, (ncclComm_t)c->comm, s);
+    if (r != ncclSuccess) { set_err(c, "ncclAllReduce failed: %s", ncclGetErrorString(r)); return CAFE_ERR_DEVICE; }
+    return CAFE_OK;
+}
+
+void comm_release(cafe_ctx* c) {
+    if (c->comm && c->comm_owned) ncclCommDestroy((ncclComm_t)c->comm);
+    c->comm = nullptr;
+    c->comm_owned = false;
+    c->comm_world = 1;
+    c->comm_rank = 0;
+}
+
+namespace {
+
+struct TreeShape {
+    int n = 0, root = -1;
+    std::vector<std::vector<int>> children;
+    std::vector<int> leaf_taxon;
+};
+
+int read_tree(const cafe_problem* p, TreeShape& t) {
+    if (!p || p->n_nodes < 3 || !p->parent || !p->leaf_taxon || !p->counts || p->n_families < 1 || p->n_taxa < 1) return CAFE_ERR_ARGUMENT;
+    t.n = p->n_nodes;
+    t.children.assign(t.n, {});
+    t.leaf_taxon.assign(p->leaf_taxon, p->leaf_taxon + t.n);
+    for (int v = 0; v < t.n; ++v) {
+        const int par = p->parent[v];
+        if (par < 0) { if (t.root >= 0) return CAFE_ERR_ARGUMENT; t.root = v; }
+        else if (par >= t.n || par <= v) return CAFE_ERR_ARGUMENT;
+        else t.children[par].push_back(v);
+    }
+    if (t.root < 0) return CAFE_ERR_ARGUMENT;
+    for (int v = 0; v < t.n; ++v)
+        if (t.children[v].empty() != (t.leaf_taxon[v] >= 0) || t.leaf_taxon[v] >= p->n_taxa) return CAFE_ERR_ARGUMENT;
+    return CAFE_OK;
+}
+
+}  // namespace
+
+// Shard plan.  prev[v][i]: for interior non-root node v, the previous position (in shard order) whose leaf counts under
+// v equal those of position i, or -1: a shard [a, b) then holds #{i in [a,b) : prev[v][i] < a} distinct columns at v.
+struct ShardModel {
+    TreeShape tree;
+    int64_t F = 0;
+    std::vector<int64_t> order;                    // shard order -> family
+    std::vector<int> nodes;                        // interior non-root nodes
+    std::vector<std::vector<int64_t>> prev;        // [nodes.size()][F]
+    int rows_inner = 0, rows_root = 0;
+};
+
+int build_shard_model(const cafe_problem* p, ShardModel& m) {
+    const int rc = read_tree(p, m.tree);
+    if (rc != CAFE_OK) return rc;
+    const int T = p->n_taxa;
+    const int64_t F = m.F = p->n_families;
+    m.rows_inner = p->max_family_size + 1;
+    m.rows_root = p->max_root_family_size;
+    // look-alikes next to each other: total size, then the rows lexicographically (stable: equal rows keep table order)
+    std::vector<int64_t> total(F, 0);
+    for (int64_t f = 0; f < F; ++f)
+        for (int t = 0; t < T; ++t) total[f] += p->counts[f * T + t];
+    m.order.resize(F);
+    std::iota(m.order.begin(), m.order.end(), (int64_t)0);
+    std::stable_sort(m.order.begin(), m.order.end(), [&](int64_t a, int64_t b) {
+        if (total[a] != total[b]) return total[a] < total[b];
+        return std::lexicographical_compare(p->counts + a * T, p->counts + (a + 1) * T, p->counts + b * T, p->counts + (b + 1) * T);
+    });
+    // pattern ids per node in shard order, children first (key = the children's ids and leaf counts)
+    std::vector<std::vector<int32_t>> pid(m.tree.n);
+    for (int v = 0; v < m.tree.n; ++v) {
+        if (m.tree.leaf_taxon[v] >= 0 || v == m.tree.root) continue;
+        std::vector<int> inner, leaves;
+        for (int u : m.tree.children[v]) (m.tree.leaf_taxon[u] < 0 ? inner : leaves).push_back(u);
+        const size_t kw = inner.size() + leaves.size();
+        std::unordered_map<std::string, std::pair<int32_t, int64_t>> seen;     // key -> (pattern id, last position)
+        seen.reserve((size_t)F * 2);
+        pid[v].resize(F);
+        std::vector<int64_t> pv(F);
+        std::vector<int32_t> key(kw);
+        for (int64_t i = 0; i < F; ++i) {
+            size_t k = 0;
+            for (int u : inner) key[k++] = pid[u][i];
+            for (int u : leaves) key[k++] = p->counts[m.order[i] * T + m.tree.leaf_taxon[u]];
+            std::string ks(reinterpret_cast<const char*>(key.data()), sizeof(int32_t) * kw);
+            auto it = seen.find(ks);
+            if (it == seen.end()) {
+                pv[i] = -1;
+                pid[v][i] = (int32_t)seen.size();
+                seen.emplace(std::move(ks), std::make_pair(pid[v][i], i));
+            } else {
+                pv[i] = it->second.second;
+                pid[v][i] = it->second.first;
+                it->second.second = i;
+            }
+        }
+        m.nodes.push_back(v);
+        m.prev.push_back(std::move(pv));
+    }
+    return CAFE_OK;
+}
+
+// Predicted device time of the shard [a, b) in arbitrary units: per interior branch one GEMM over the node's distinct
+// columns (padded to the 128-column tile) -- 2*rows*(M+1) flop per column -- plus the gather/assemble traffic of the
+// parent's panel, both linear in the padded columns; the root's children run over one column per family.
+double shard_cost(const ShardModel& m, int64_t a, int64_t b) {
+    double cost = 0;
+    for (size_t j = 0; j < m.nodes.size(); ++j) {
+        const std::vector<int64_t>& pv = m.prev[j];
+        int64_t cols = 0;
+        for (int64_t i = a; i < b; ++i) cols += pv[i] < a;
+        cost += (double)round_up64(cols, kBN);
+    }
+    return cost;
+}
+
+int plan_shards(const ShardModel& m, int n_shards, std::vector<int64_t>& bounds) {
+    const int64_t F = m.F;
+    if (n_shards < 1 || n_shards > F) return CAFE_ERR_ARGUMENT;
+    bounds.assign(n_shards + 1, 0);
+    bounds[n_shards] = F;
+    if (n_shards == 1) return CAFE_OK;
+    // start: equal cumulative cost, a family's cost being the number of nodes at which it is the first of the whole
+    // table (in shard order) to show its pattern
+    std::vector<double> cum(F, 0.0);
+    for (size_t j = 0; j < m.nodes.size(); ++j)
+        for (int64_t i = 0; i < F; ++i) cum[i] += m.prev[j][i] < 0;
+    for (int64_t i = 1; i < F; ++i) cum[i] += cum[i - 1];
+    for (int r = 1; r < n_shards; ++r)
+        bounds[r] = std::lower_bound(cum.begin(), cum.end(), cum[F - 1] * r / n_shards) - cum.begin();
+    auto fix = [&]() {                                   // never an empty shard
+        for (int r = 1; r < n_shards; ++r) bounds[r] = std::max(bounds[r], bounds[r - 1] + 1);
+        for (int r = n_shards - 1; r >= 1; --r) bounds[r] = std::min(bounds[r], bounds[r + 1] - 1);
+    };
+    fix();
+    // refine: a pattern shared across a cut is paid on both sides, which the start ignores.  Move every cut towards
+    // the cheaper neighbour in proportion to the imbalance; a handful of sweeps brings the shards within a percent.
+    std::vector<double> cost(n_shards);
+    std::vector<int64_t> best = bounds;
+    double best_spread = 1e300;
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        double lo = 1e300, hi = 0;
+        for (int r = 0; r < n_shards; ++r) { cost[r] = shard_cost(m, bounds[r], bounds[r + 1]); lo = std::min(lo, cost[r]); hi = std::max(hi, cost[r]); }
+        if (hi / lo < best_spread) { best_spread = hi / lo; best = bounds; }
+        if (hi / lo < 1.005) break;
+        std::vector<int64_t> nb = bounds;
+        for (int r = 1; r < n_shards; ++r) {
+            // cut r separates shards r-1 and r: shift it by the family count that evens their costs out at their
+            // present average cost per family, damped
+            const double cl = cost[r - 1], cr = cost[r];
+            const double per_l = cl / (double)(bounds[r] - bounds[r - 1]), per_r = cr / (double)(bounds[r + 1] - bounds[r]);
+            const double shift = 0.5 * (cr - cl) / (per_l + per_r);
+            nb[r] = bounds[r] + (int64_t)std::llround(0.7 * shift);
+        }
+        bounds = nb;
+        bounds[0] = 0; bounds[n_shards] = F;
+        fix();
+    }
+    bounds = best;
+    return CAFE_OK;
+}
+
+}  // namespace cafe
+
+// ---------------------------------------------------------------------------------------------------------------
+struct cafe_sharded {
+    std::vector<cafe_ctx*> ctx;
+    std::vector<int> devices;
+    std::vector<int64_t> order, bounds;
+    int64_t F = 0;
+    std::string err;
+    // one host thread per device
+    struct Worker {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::function<void()> job;
+        bool pending = false, quit = false;
+    };
+    std::vector<Worker*> workers;
+    void run_all(const std::function<void(int)>& fn) {
+        for (size_t r = 0; r < workers.size(); ++r) {
+            Worker* w = workers[r];
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->job = [fn, r]() { fn((int)r); };
+            w->pending = true;
+            w->cv.notify_all();
+        }
+        for (Worker* w : workers) {
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv.wait(lk, [w] { return !w->pending; });
+        }
+    }
+    void start_workers(int n) {
+        for (int r = 0; r < n; ++r) {
+            Worker* w = new Worker();
+            w->th = std::thread([w]() {
+                for (;;) {
+                    std::unique_lock<std::mutex> lk(w->mu);
+                    w->cv.wait(lk, [w] { return w->pending || w->quit; });
+                    if (w->quit) return;
+                    std::function<void()> job = std::move(w->job);
+                    lk.unlock();
+                    job();
+                    lk.lock();
+                    w->pending = false;
+                    w->cv.notify_all();
+                }
+            });
+            workers.push_back(w);
+        }
+    }
+    void stop_workers() {
+        for (Worker* w : workers) {
+            { std::lock_guard<std::mutex> lk(w->mu); w->quit = true; w->cv.notify_all(); }
+            w->th.join();
+            delete w;
+        }
+        workers.clear();
+    }
+};
+
+extern "C" {
+
+int cafe_comm_unique_id(char id[CAFE_COMM_ID_BYTES]) {
+    if (!id) return CAFE_ERR_ARGUMENT;
+    ncclUniqueId u;
+    if (ncclGetUniqueId(&u) != ncclSuccess) return CAFE_ERR_DEVICE;
+    std::memset(id, 0, CAFE_COMM_ID_BYTES);
+    std::memcpy(id, &u, sizeof u);
+    return CAFE_OK;
+}
+
+int cafe_comm_attach(cafe_ctx* ctx, const char id[CAFE_COMM_ID_BYTES], int32_t world_size, int32_t rank) {
+    if (!ctx) return CAFE_ERR_ARGUMENT;
+    if (!id || world_size < 1 || rank < 0 || rank >= world_size) { cafe::set_err(ctx, "cafe_comm_attach: bad id / world size / rank"); return CAFE_ERR_ARGUMENT; }
+    cafe::comm_release(ctx);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof u);
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = ncclCommInitRank(&comm, world_size, u, rank);
+    if (r != ncclSuccess) { cafe::set_err(ctx, "ncclCommInitRank failed: %s", ncclGetErrorString(r)); return CAFE_ERR_DEVICE; }
+    ctx->comm = comm;
+    ctx->comm_owned = true;
+    ctx->comm_world = world_size;
+    ctx->comm_rank = rank;
+    return CAFE_OK;
+}
+
+int cafe_comm_detach(cafe_ctx* ctx) {
+    if (!ctx) return CAFE_ERR_ARGUMENT;
+    if (ctx->device_ready) { (void)hipSetDevice(ctx->device); if (ctx->stream) (void)hipStreamSynchronize(ctx->stream); }
+    cafe::comm_release(ctx);
+    return CAFE_OK;
+}
+
+int cafe_shard_plan(const cafe_problem* problem, int32_t n_shards, int64_t* order, int64_t* bounds) {
+    if (!problem || !order || !bounds || n_shards < 1) return CAFE_ERR_ARGUMENT;
+    try {
+        cafe::ShardModel m;
+        int rc = cafe::build_shard_model(problem, m);
+        if (rc != CAFE_OK) return rc;
+        std::vector<int64_t> b;
+        rc = cafe::plan_shards(m, n_shards, b);
+        if (rc != CAFE_OK) return rc;
+        std::copy(m.order.begin(), m.order.end(), order);
+        std::copy(b.begin(), b.end(), bounds);
+        return CAFE_OK;
+    } catch (const std::exception&) {
+        return CAFE_ERR_MEMORY;
+    }
+}
+
+cafe_sharded* cafe_create_sharded(const cafe_problem* problem, const int32_t* devices, int32_t n_devices, char* err, size_t errlen) {
+    auto fail = [&](const std::string& msg) -> cafe_sharded* {
+        if (err && errlen) std::snprintf(err, errlen, "%s", msg.c_str());
+        return nullptr;
+    };
+    if (!problem || !devices || n_devices < 1) return fail("cafe_create_sharded: problem, devices and n_devices >= 1 are required");
+    if (n_devices > problem->n_families) return fail("cafe_create_sharded: more devices than families");
+    for (int i = 0; i < n_devices; ++i)
+        for (int j = 0; j < i; ++j)
+            if (devices[i] == devices[j]) return fail("cafe_create_sharded: a device is listed twice (RCCL needs one rank per device)");
+    cafe_sharded* s = nullptr;
+    try {
+        s = new cafe_sharded();
+        s->F = problem->n_families;
+        s->order.resize(s->F);
+        s->bounds.resize(n_devices + 1);
+        if (cafe_shard_plan(problem, n_devices, s->order.data(), s->bounds.data()) != CAFE_OK) { delete s; return fail("cafe_create_sharded: malformed problem"); }
+        s->devices.assign(devices, devices + n_devices);
+        s->ctx.assign(n_devices, nullptr);
+        s->start_workers(n_devices);
+        const int T = problem->n_taxa;
+        std::vector<std::string> errs(n_devices);
+        s->run_all([&](int r) {                              // the contexts are built concurrently, each by the thread that will drive it
+            const int64_t lo = s->bounds[r], n = s->bounds[r + 1] - lo;
+            std::vector<int32_t> counts((size_t)n * T);
+            for (int64_t i = 0; i < n; ++i) std::memcpy(&counts[(size_t)i * T], problem->counts + s->order[lo + i] * T, sizeof(int32_t) * T);
+            cafe_problem pb = *problem;
+            pb.counts = counts.data();
+            pb.n_families = n;
+            pb.device = s->devices[r];
+            char e[512] = {0};
+            s->ctx[r] = cafe_create(&pb, e, sizeof e);
+            if (!s->ctx[r]) errs[r] = e;
+        });
+        for (int r = 0; r < n_devices; ++r)
+            if (!s->ctx[r]) { const std::string msg = "cafe_create_sharded: shard " + std::to_string(r) + ": " + errs[r]; cafe_sharded_destroy(s); return fail(msg); }
+        std::vector<ncclComm_t> comms(n_devices);
+        const ncclResult_t nr = ncclCommInitAll(comms.data(), n_devices, s->devices.data());
+        if (nr != ncclSuccess) { const std::string msg = std::string("cafe_create_sharded: ncclCommInitAll failed: ") + ncclGetErrorString(nr); cafe_sharded_destroy(s); return fail(msg); }
+        for (int r = 0; r < n_devices; ++r) { s->ctx[r]->comm = comms[r]; s->ctx[r]->comm_owned = true; s->ctx[r]->comm_world = n_devices; s->ctx[r]->comm_rank = r; }
+    } catch (const std::exception& e) {
+        if (s) cafe_sharded_destroy(s);
+        return fail(std::string("cafe_create_sharded: ") + e.what());
+    }
+    if (err && errlen) err[0] = 0;
+    return s;
+}
+
+void cafe_sharded_destroy(cafe_sharded* s) {
+    if (!s) return;
+    for (cafe_ctx* c : s->ctx) if (c) cafe_destroy(c);      // releases the communicators as well
+    s->stop_workers();
+    delete s;
+}
+
+const char* cafe_sharded_last_error(const cafe_sharded* s) { return s ? s->err.c_str() : "null sharded context"; }
+int32_t cafe_sharded_size(const cafe_sharded* s) { return s ? (int32_t)s->ctx.size() : 0; }
+cafe_ctx* cafe_sharded_context(cafe_sharded* s, int32_t r) { return (s && r >= 0 && r < (int32_t)s->ctx.size()) ? s->ctx[r] : nullptr; }
+
+int cafe_sharded_score(cafe_sharded* s, const cafe_params* params, double* neg_lnl, const cafe_family_out* out) {
+    if (!s || !neg_lnl) return CAFE_ERR_ARGUMENT;
+    const int n = (int)s->ctx.size();
+    std::vector<int> rc(n, CAFE_OK);
+    std::vector<double> value(n, 0.0);
+    // every worker: enqueue its shard, all-reduce the pair on its stream, read it back.  The all-reduce makes the call
+    // collective; argument errors are detected identically on every shard before anything is enqueued.
+    s->run_all([&](int r) { rc[r] = cafe_score(s->ctx[r], params, &value[r], nullptr); });
+    for (int r = 0; r < n; ++r)
+        if (rc[r] != CAFE_OK) { s->err = "shard " + std::to_string(r) + ": " + cafe_last_error(s->ctx[r]); return rc[r]; }
+    *neg_lnl = value[0];                                     // identical on every rank after the all-reduce
+    if (out) return cafe_sharded_family_results(s, out);
+    return CAFE_OK;
+}
+
+int cafe_sharded_family_results(cafe_sharded* s, const cafe_family_out* out) {
+    if (!s || !out) return CAFE_ERR_ARGUMENT;
+    const int n = (int)s->ctx.size();
+    std::vector<int> rc(n, CAFE_OK);
+    int K = 1;
+    for (cafe_ctx* c : s->ctx) K = std::max(K, c->K_last);
+    s->run_all([&](int r) {
+        const int64_t lo = s->bounds[r], nf = s->bounds[r + 1] - lo;
+        std::vector<double> lnl, cat, lik;
+        std::vector<int32_t> failed;
+        cafe_family_out o = {};
+        if (out->family_lnl) { lnl.resize(nf); o.family_lnl = lnl.data(); }
+        if (out->category_likelihood) { cat.resize((size_t)nf * K); o.category_likelihood = cat.data(); }
+        if (out->family_likelihood) { lik.resize(nf); o.family_likelihood = lik.data(); }
+        if (out->failed) { failed.resize(nf); o.failed = failed.data(); }
+        rc[r] = cafe_family_results(s->ctx[r], &o);
+        if (rc[r] != CAFE_OK) return;
+        const bool gamma = s->ctx[r]->model_last == CAFE_MODEL_GAMMA;
+        for (int64_t i = 0; i < nf; ++i) {                   // shards write disjoint families
+            const int64_t f = s->order[lo + i];
+            if (out->family_lnl) out->family_lnl[f] = lnl[i];
+            if (gamma && out->family_likelihood) out->family_likelihood[f] = lik[i];
+            if (gamma && out->category_likelihood) std::memcpy(out->category_likelihood + f * K, &cat[(size_t)i * K], sizeof(double) * K);
+            if (out->failed) out->failed[f] = failed[i];
+        }
+    });
+    for (int r = 0; r < n; ++r)
+        if (rc[r] != CAFE_OK) { s->err = "shard " + std::to_string(r) + ": " + cafe_last_error(s->ctx[r]); return rc[r]; }
+    return CAFE_OK;
+}
+
+}  // extern "C"

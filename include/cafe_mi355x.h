@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CAFE_ABI_VERSION 1
+#define CAFE_ABI_VERSION 2
 #define CAFE_MAX_CATEGORIES 32
 
 typedef struct cafe_ctx cafe_ctx;
@@ -146,6 +146,44 @@ int cafe_score(cafe_ctx* ctx, const cafe_params* params, double* neg_lnl, const 
 int cafe_score_partial(cafe_ctx* ctx, const cafe_params* params, double* device_partial, void* hip_stream);
 /* Turns the all-reduced pair into the scorer value: +inf if partial[1] > 0 else -partial[0]. */
 double cafe_finish_partial(const double host_partial[2]);
+
+/* ---- Multi-GPU: families shard across the GPUs of a node, every GPU builds all matrices, and ONE
+ * all-reduce (RCCL over xGMI) of the pair {sum lnL, rejects} closes a scorer call.  The reference has no counterpart:
+ * its family loops are OpenMP (base_model.cpp:81-107, gamma_core.cpp:201-244).  Two ways to use it:
+ *
+ * (1) one process per GPU (torchrun, MPI, ...): every rank creates its context over ITS shard of the families (any
+ *     partition gives the same -lnL; cafe_shard_plan balances the ranks), rank 0 makes an id with cafe_comm_unique_id
+ *     and hands it to the others by whatever channel the launcher offers, and every rank calls cafe_comm_attach.  From
+ *     then on cafe_score on every rank ends with ncclAllReduce(pair, 2 doubles, sum) on the context's stream and returns
+ *     the WHOLE table's value on every rank; per-family results stay per shard.  Calls are collective: every rank must
+ *     make the same sequence of cafe_score calls. */
+#define CAFE_COMM_ID_BYTES 128
+int cafe_comm_unique_id(char id[CAFE_COMM_ID_BYTES]);
+int cafe_comm_attach(cafe_ctx* ctx, const char id[CAFE_COMM_ID_BYTES], int32_t world_size, int32_t rank);
+int cafe_comm_detach(cafe_ctx* ctx);
+
+/* Balanced family partition for n_shards GPUs.  The device's unit of work is the DISTINCT pattern of leaf counts under
+ * an interior node (cafe_create shares likelihood columns between families that agree on a whole subtree), so families
+ * are ordered to put look-alikes next to each other (total size, then lexicographically) and cut into consecutive runs
+ * of equal predicted device time.  order[n_families]: family indices in shard order; bounds[n_shards + 1]: shard r owns
+ * order[bounds[r] .. bounds[r+1]).  Pure host code (no device needed); deterministic, so every rank derives the same
+ * plan.  Only tree, counts and max sizes of `problem` are read. */
+int cafe_shard_plan(const cafe_problem* problem, int32_t n_shards, int64_t* order, int64_t* bounds);
+
+/* (2) one process, several GPUs: cafe_create_sharded plans the shards (cafe_shard_plan), creates one context per device
+ *     of `devices` -- each driven by its own host thread and stream -- and joins them in one communicator
+ *     (ncclCommInitAll).  cafe_sharded_score = model::infer_family_likelihoods over the whole table: all devices
+ *     prune their shard concurrently, one all-reduce, one value.  problem->device is ignored. */
+typedef struct cafe_sharded cafe_sharded;
+cafe_sharded* cafe_create_sharded(const cafe_problem* problem, const int32_t* devices, int32_t n_devices, char* err, size_t errlen);
+void      cafe_sharded_destroy(cafe_sharded* s);
+const char* cafe_sharded_last_error(const cafe_sharded* s);
+int cafe_sharded_score(cafe_sharded* s, const cafe_params* params, double* neg_lnl, const cafe_family_out* out);
+/* per-family results of the last call, in the problem's family order (gathered from the shards) */
+int cafe_sharded_family_results(cafe_sharded* s, const cafe_family_out* out);
+int32_t cafe_sharded_size(const cafe_sharded* s);
+/* shard r's context (owned by s): statistics, introspection */
+cafe_ctx* cafe_sharded_context(cafe_sharded* s, int32_t r);
 
 /* Per-family results of the last call (valid after the stream was synchronised). */
 int cafe_family_results(cafe_ctx* ctx, const cafe_family_out* out);
