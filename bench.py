@@ -8,16 +8,28 @@ transition matrix, prune every family x gamma category, reduce to -lnL, all-redu
 Workload (BASELINE.json configs[3], the configuration the metric is quoted on; it fits one GPU):
 synthetic 50 000 families / 100 taxa / max family size 600 (M=720, R=750, matrix order 751), gamma
 model K=8, from cafexp_amd/synth.py (seed 20251004), scored at lambda=0.002, alpha=2.0.  Strong
-scaling: the 50 000 families are sharded contiguously over the N ranks (one process per GPU), each
-rank builds all matrices, and one RCCL all-reduce of {sum lnL, rejects} closes the call.
+scaling: the 50 000 families are sharded over the N ranks by the library's plan (cafe_shard_plan), one
+process per GPU, each rank builds all matrices, and ONE RCCL all-reduce of {sum lnL, rejects} -- issued
+inside cafe_score by the library itself (cafe_comm_attach) -- closes the call.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (fp64 MFMA, from
-HIP events the library records around every K2 launch in the timed region) and `cpu_baseline`
-(the CPU restatement of the reference algorithm timed on this host's cores on a bounded sample).
+`python bench.py --gpus N` run plainly starts its N ranks itself (torch.distributed.run as a child
+process, before this process touches torch or the GPU) and relays rank 0's JSON line; launched under
+torch.distributed.run it is one of the ranks.  `--single-process` drives the N GPUs from ONE process
+instead (cafe_create_sharded: a host thread and stream per device, ncclCommInitAll).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (fp64 MFMA, from HIP
+events the library records around every K2 launch in the timed region) and, at N = 1, `cpu_baseline`
+(the CPU restatement of the reference algorithm timed on this host's cores on a bounded sample),
+`parity_sample` (the CPU-pruned families against the GPU's values for the same families, and the
+reference-algorithm matrices against the GPU's), `one_column_per_family` (the same call without the
+subtree-level column sharing: the data-independent figure) and `other_configs` (BASELINE configs 2, 3
+on the mammals fixture and config 5's shape).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,6 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6      # AMD MI355X datasheet: FP64 matrix = FP64 vector = 78.6 TFLOP/s
+PARITY_TOL = 1e-10                # per-family values against the CPU restatement (BASELINE asks 1e-6 on -lnL)
 
 
 def parse():
@@ -40,54 +53,152 @@ def parse():
     ap.add_argument("--lam", type=float, default=0.002)
     ap.add_argument("--alpha", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip one_column_per_family and other_configs (N = 1 only)")
+    ap.add_argument("--single-process", action="store_true", help="N > 1: one process drives all GPUs (cafe_create_sharded)")
     ap.add_argument("--emulate-shard", default="", help="R/W: rehearsal on one GPU of what rank R of W would run (no collective)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl = RCCL over xGMI (the real thing); gloo only to rehearse the N>1 path on a box with fewer GPUs than ranks")
+                    help="nccl = RCCL over xGMI, issued by the library (the real thing); gloo: rehearsal of the N>1 path on a box "
+                         "with fewer GPUs than ranks (all ranks share GPU 0, the pair is summed on the host)")
     ap.add_argument("--cpu-matrices", type=int, default=3, help="matrices built by the O(N^3) reference algorithm in the CPU sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU sample (0 = the host CPU share)")
     ap.add_argument("--cpu-families", type=int, default=0, help="families pruned in the CPU sample (0 = 4 per host thread)")
     return ap.parse_args()
 
 
-def cpu_baseline(pb, pr, args, n_matrices_call):
+def launch_ranks(args):
+    """N > 1 and not under a launcher: start the ranks as children BEFORE anything here touches the GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    for ln in p.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if line:
+        print(line[-1], flush=True)
+    return p.returncode if p.returncode else (0 if line else 1)
+
+
+def cpu_baseline(pb, pr, args, n_matrices_call, ctx_values):
     """CPU restatement of the reference path (oracle/, "port") on a bounded sample, all host cores.
     matrices: the reference's O(N^3) log-space entries (matrix_cache.cpp:121); prune: per-family
-    post-order mat-vecs (core.cpp:133).  Extrapolated linearly to the whole call."""
+    post-order mat-vecs (core.cpp:133).  Extrapolated linearly to the whole call.  The sample is also the
+    full-size parity check: the pruned families' values and the O(N^3) matrices against the GPU's."""
     import dataclasses
     import numpy as np
     from oracle import oracle as O
     threads = min(O.host_cpu_share(), args.cpu_threads or 10 ** 6)
     O.set_threads(threads)                            # OpenMP would otherwise take every logical CPU of the host
     n = pb.matrix_size
-    ts = sorted({float(t) for t in pb.branch_length if t > 0})
-    pick = [ts[(i * len(ts)) // args.cpu_matrices] for i in range(args.cpu_matrices)]
-    t_mat = O.time_matrices(n, args.lam, pick, fast=False)
+    K = 1 if pr.multipliers is None else len(pr.multipliers)
+    # matrices: branches spread over the tree; category 0 carries the smallest multiplier, K-1 the largest
+    branches = [v for v in range(pb.n_nodes) if pb.parent[v] >= 0 and pb.branch_length[v] > 0]
+    pick = [branches[(i * len(branches)) // args.cpu_matrices] for i in range(args.cpu_matrices)]
+    mat_rel = 0.0
+    t_mat = 0.0
+    for i, v in enumerate(pick):
+        k = (i * max(1, K - 1)) // max(1, args.cpu_matrices - 1) if K > 1 else 0
+        lam = float(pr.lambdas[pb.lambda_index[v]]) * (float(pr.multipliers[k]) if pr.multipliers is not None else 1.0)
+        t0 = time.perf_counter()
+        want = O.build_matrix(n, lam, float(pb.branch_length[v]), fast=False)      # O(N^3), OpenMP over rows
+        t_mat += time.perf_counter() - t0
+        got = ctx_values["matrix"](v, k)
+        cols = n if pb.leaf_taxon[v] >= 0 else pb.max_family_size + 1               # interior branches: columns <= M only
+        sel = want[:, :cols] > 1e-290                                               # (below that the O(N^3) sum itself loses digits)
+        mat_rel = max(mat_rel, float(np.max(np.abs(got[:, :cols][sel] / want[:, :cols][sel] - 1.0))))
     per_matrix = t_mat / len(pick)
     nf = args.cpu_families or 4 * threads
     nf = min(nf, pb.n_families)
-    sub = dataclasses.replace(pb, counts=pb.counts[:nf].copy(), family_ids=pb.family_ids[:nf])
-    O.score(sub, pr, fast=True)                       # matrices by the O(N^2) build: only the prune is timed
+    sel = np.unique(np.linspace(0, pb.n_families - 1, nf).astype(np.int64))       # spread over the table
+    sub = dataclasses.replace(pb, counts=pb.counts[sel].copy(), family_ids=[pb.family_ids[i] for i in sel])
+    if pr.multipliers is not None:
+        _, cat, fam = O.score_gamma(sub, pr, fast=True, per_family=True)            # matrices by the O(N^2) build: only the prune is timed
+        got_fam = ctx_values["family_likelihood"][sel]
+        got_cat = ctx_values["category_likelihood"][sel]
+        fam_rel = float(np.max(np.abs(got_fam / fam - 1.0)))
+        ok = cat > 0
+        fam_rel = max(fam_rel, float(np.max(np.abs(got_cat[ok] / cat[ok] - 1.0))))
+    else:
+        _, fam = O.score_base(sub, pr, fast=True, per_family=True)
+        fam_rel = float(np.max(np.abs(ctx_values["family_lnl"][sel] / fam - 1.0)))
     t_m, t_all = O.last_timings()
-    per_family = (t_all - t_m) / nf                   # all K categories of one family, on `threads` threads
+    per_family = (t_all - t_m) / len(sel)             # all K categories of one family, on `threads` threads
     call_s = per_matrix * n_matrices_call + per_family * pb.n_families
-    K = 1 if pr.multipliers is None else len(pr.multipliers)
-    return {
+    base = {
         "value": pb.n_families / call_s, "unit": "families/s", "cores": threads, "kind": "port",
         "sample": "%d of %d transition matrices (order %d, reference O(N^3) algorithm, %.2f s each) + %d of %d families x %d "
                   "categories pruned (%.3f s per family); whole call extrapolated linearly to %.0f s"
-                  % (len(pick), n_matrices_call, n, per_matrix, nf, pb.n_families, K, per_family, call_s),
+                  % (len(pick), n_matrices_call, n, per_matrix, len(sel), pb.n_families, K, per_family, call_s),
     }
+    parity = {"families_checked": int(len(sel)), "family_values_max_rel": fam_rel, "matrices_checked": len(pick),
+              "matrix_entries_max_rel": mat_rel, "tolerance": PARITY_TOL,
+              "against": "oracle/ CPU restatement: per-family (and per-category) likelihoods of the sampled families; "
+                         "matrix entries against the reference's O(N^3) log-space sum"}
+    return base, parity
+
+
+def timed_calls(fn, reps):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        v = fn()
+    return (time.perf_counter() - t0) / reps, v
+
+
+def other_configs(args):
+    """BASELINE configs 2, 3 (mammals fixture) and the shape of config 5, each a few timed calls on GPU 0."""
+    import numpy as np
+    from cafexp_amd import capi, problem as P, synth
+    from cafexp_amd.gamma_rates import discrete_gamma
+    out = {}
+    data = os.path.join(ROOT, "tests", "golden", "data")
+    rd = lambda n: open(os.path.join(data, n)).read()
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_golden.json")))["scores"]
+    tree = P.parse_newick(rd("mammals_tree.txt"))
+    species, ids, counts = P.read_family_table(rd("mammal_gene_families.txt"))
+    pb = P.build_problem(tree, species, ids, counts)
+    prior = P.prior_uniform(pb.max_root_family_size)
+    ctx = capi.Context(pb, max_categories=4)
+    ctx.set_profiling(False)
+    for name, gold, pr, alpha in [
+        ("config2_mammals_base", "mammals_base_l0.01", P.Params(lambdas=np.array([0.01]), prior=prior), 1.0),
+        ("config3_mammals_gamma_k4", "mammals_gamma_k4_a2",
+         (lambda pm: P.Params(lambdas=np.array([0.005]), prior=prior, multipliers=pm[1], cat_probs=pm[0]))(discrete_gamma(4, 2.0)), 2.0),
+    ]:
+        sec, v = timed_calls(lambda: ctx.score(pr, alpha=alpha), 50)
+        ref = golden[gold]["neg_lnl"]
+        out[name] = {"families": pb.n_families, "ms_per_call": 1e3 * sec, "families_per_s": pb.n_families / sec, "neg_lnl": v,
+                     "rel_err_vs_reference": abs(v - ref) / abs(ref), "reference_neg_lnl": ref}
+    ctx.close()
+    # config 5: lambda tree with two rates + 3-tap error model, base model, 100 000 families (the bench's generator)
+    pb5, _ = synth.make_problem(n_taxa=args.taxa, n_families=2 * args.families, max_count=args.max_count, lambda_clade_min=10, n_deviations=3)
+    em = P.error_model_table(P.default_error_model(pb5.max_family_size)[:1] + [[0.05, 0.9, 0.05]], pb5.max_family_size)
+    pr5 = P.Params(lambdas=np.array([args.lam, 2 * args.lam]), prior=P.prior_uniform(pb5.max_root_family_size), error_model=em)
+    ctx = capi.Context(pb5)
+    ctx.set_profiling(False)
+    sec, v = timed_calls(lambda: ctx.score(pr5), 3)
+    out["config5_shape_two_lambdas_error_model"] = {"families": pb5.n_families, "ms_per_call": 1e3 * sec, "families_per_s": pb5.n_families / sec,
+                                                    "neg_lnl": v, "rel_err_vs_reference": None}
+    ctx.close()
+    return out
 
 
 def main():
     args = parse()
+    under_launcher = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not under_launcher and not args.single_process and not args.emulate_shard:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if under_launcher:
         args.gpus = world
+    n_gpus = args.gpus
 
     import dataclasses
     import numpy as np
@@ -96,11 +207,12 @@ def main():
     from cafexp_amd import capi, problem as P, synth
     from cafexp_amd.gamma_rates import discrete_gamma
 
-    device = local_rank % torch.cuda.device_count()          # == local_rank on a real N-GPU launch
+    native_comm = world > 1 and args.backend == "nccl"
+    device = local_rank % max(1, torch.cuda.device_count()) if native_comm or world == 1 else 0
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
+        if native_comm:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -113,26 +225,45 @@ def main():
         pr = P.Params(lambdas=np.array([args.lam]), prior=P.prior_uniform(pb.max_root_family_size), multipliers=mult, cat_probs=probs)
     else:
         pr = P.Params(lambdas=np.array([args.lam]), prior=P.prior_uniform(pb.max_root_family_size))
-    # every rank computes the same partition; shards are balanced by distinct subtree patterns (the device's unit of
-    # work), not by family count
-    if args.emulate_shard:
-        er, ew = (int(x) for x in args.emulate_shard.split("/"))
-        mine = P.shard_families_by_pattern_cost(pb, ew)[er]
+
+    sharded = None
+    if args.single_process and n_gpus > 1:
+        sharded = capi.Sharded(pb, list(range(n_gpus)), max_categories=max(1, K))
+        ctx = sharded.shard(0)
+        for r in range(n_gpus):
+            sharded.shard(r).set_profiling(r == 0)
     else:
-        mine = P.shard_families_by_pattern_cost(pb, world)[rank]
-    shard = dataclasses.replace(pb, counts=np.ascontiguousarray(pb.counts[mine]), family_ids=[pb.family_ids[i] for i in mine])
-    ctx = capi.Context(shard, max_categories=max(1, K), device=device)
+        # every rank derives the same plan; shards are balanced by predicted device time (distinct subtree patterns)
+        if args.emulate_shard:
+            er, ew = (int(x) for x in args.emulate_shard.split("/"))
+            mine = capi.shard_plan(pb, ew)[er]
+        elif world > 1:
+            mine = capi.shard_plan(pb, world)[rank]
+        else:
+            mine = np.arange(F)
+        shard = pb if len(mine) == F and world == 1 else dataclasses.replace(
+            pb, counts=np.ascontiguousarray(pb.counts[mine]), family_ids=[pb.family_ids[i] for i in mine])
+        ctx = capi.Context(shard, max_categories=max(1, K), device=device)
+        ctx.set_profiling(True)
+        if native_comm:
+            # the communicator of the data path lives in the library: rank 0's id travels over the launcher's channel
+            idt = torch.zeros(capi.CAFE_COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            ctx.comm_attach(bytes(idt.cpu().numpy().tobytes()), world, rank)
 
     buf = torch.zeros(2, dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream()
 
     def step():
-        ctx.score_partial(pr, buf.data_ptr(), stream.cuda_stream, alpha=args.alpha)
-        if world > 1 and args.backend == "nccl":
-            dist.all_reduce(buf)                      # RCCL over xGMI: {sum lnL, rejects}
-        pair = buf.cpu()                              # host read-back = the scorer's return value
-        if world > 1 and args.backend != "nccl":
-            dist.all_reduce(pair)
+        if sharded is not None:
+            return sharded.score(pr, alpha=args.alpha)
+        if world == 1 or native_comm:
+            return ctx.score(pr, alpha=args.alpha)    # N > 1: ends with the library's ncclAllReduce of {sum lnL, rejects}
+        ctx.score_partial(pr, buf.data_ptr(), stream.cuda_stream, alpha=args.alpha)       # gloo rehearsal
+        pair = buf.cpu()
+        dist.all_reduce(pair)
         return ctx.finish(pair.numpy())
 
     def fence():
@@ -157,10 +288,11 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if native_comm else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    rc = 0
     if rank == 0:
         st = ctx.stats()
         achieved = flops / (ms_gemm * 1e-3) / 1e12 if ms_gemm > 0 else 0.0
@@ -170,19 +302,20 @@ def main():
             try:
                 t = json.load(open(tpath))
                 if t.get("workload") == {"families": args.families, "taxa": args.taxa, "max_count": args.max_count,
-                                         "categories": args.categories, "gpus": world}:
+                                         "categories": args.categories, "gpus": n_gpus}:
                     traffic = t.get("prune_gemm_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
             "metric": "gene-family likelihoods/sec per optimizer_scorer call",
-            "value": F * args.steps / elapsed, "unit": "families/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": F * args.steps / elapsed, "unit": "families/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "synthetic %d families / %d taxa / max family size %d (matrix order %d), gamma K=%d, lambda=%g alpha=%g, "
-                                   "family-sharded over %d GPU(s)" % (F, args.taxa, args.max_count, pb.matrix_size, K, args.lam, args.alpha, world),
+                                   "family-sharded over %d GPU(s)" % (F, args.taxa, args.max_count, pb.matrix_size, K, args.lam, args.alpha, n_gpus),
                        "families": F, "taxa": args.taxa, "max_family_size": args.max_count, "gamma_categories": K,
-                       "parallelism": "family-shard x%d + 1 all-reduce" % world},
+                       "parallelism": "family-shard x%d + 1 RCCL all-reduce inside cafe_score (%s)"
+                                      % (n_gpus, "one process, a host thread per GPU" if sharded is not None else "one process per GPU")},
             "neg_lnl": value,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
@@ -195,12 +328,38 @@ def main():
                                    "prune_gemm": ms_gemm / args.steps},
             "n_matrices": st["n_matrices"],
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pb, pr, args, st["n_matrices"])
+        if n_gpus > 1:
+            out["roofline"]["note"] = "rank 0's shard"
+        if world == 1 and sharded is None and not args.emulate_shard:
+            if not args.no_cpu_baseline:
+                res = ctx.family_results(K if K > 1 else 0)
+                res["matrix"] = ctx.matrix
+                out["cpu_baseline"], out["parity_sample"] = cpu_baseline(pb, pr, args, st["n_matrices"], res)
+                worst = max(out["parity_sample"]["family_values_max_rel"], out["parity_sample"]["matrix_entries_max_rel"])
+                if not worst <= PARITY_TOL:
+                    print("bench.py: PARITY FAILURE at full size: %r" % out["parity_sample"], file=sys.stderr)
+                    rc = 3
+            ctx.close()
+            if not args.no_extras:
+                # the same call with one column per family at every node (no subtree-level sharing): data-independent
+                plain = capi.Context(pb, max_categories=max(1, K), device=device, subtree_dedup=False)
+                plain.set_profiling(True)
+                sec, v = timed_calls(lambda: plain.score(pr, alpha=args.alpha), 2)
+                ps = plain.stats()
+                out["one_column_per_family"] = {"ms_per_step": 1e3 * sec, "value": F / sec, "neg_lnl": v,
+                                                "prune_gemm_tflops": ps["gemm_flops"] / (ps["ms_gemm"] * 1e-3) / 1e12 if ps["ms_gemm"] > 0 else None,
+                                                "identical_to_headline": v == value}
+                plain.close()
+                out["other_configs"] = other_configs(args)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        if native_comm:
+            ctx.comm_detach()
         dist.destroy_process_group()
+    if sharded is not None:
+        sharded.close()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -54,6 +54,7 @@ class CafeStats(C.Structure):
         ("ms_reduce", C.c_double), ("gemm_flops", C.c_double), ("gemm_bytes", C.c_double), ("gemm_flops_per_family", C.c_double),
         ("gemm_launches", C.c_int64), ("n_matrices", C.c_int64), ("n_unique_families", C.c_int64),
         ("n_chunks", C.c_int64), ("matrix_bytes", C.c_int64), ("panel_bytes", C.c_int64),
+        ("n_assemble_passes", C.c_int64), ("n_gather_epilogues", C.c_int64), ("n_leaf_passes", C.c_int64),
     ]
 
     def as_dict(self):
@@ -67,7 +68,7 @@ EXPORTS = [
     "cafe_root_max", "cafe_reconstruct", "cafe_branch_probabilities", "cafe_pvalues", "cafe_debug_force_tile",
     "cafe_comm_unique_id", "cafe_comm_attach", "cafe_comm_detach", "cafe_shard_plan", "cafe_create_sharded",
     "cafe_sharded_destroy", "cafe_sharded_last_error", "cafe_sharded_score", "cafe_sharded_family_results",
-    "cafe_sharded_size", "cafe_sharded_context",
+    "cafe_sharded_size", "cafe_sharded_context", "cafe_set_graphs",
 ]
 CAFE_COMM_ID_BYTES = 128
 
@@ -135,6 +136,8 @@ def load():
     L.cafe_debug_force_tile.argtypes = [C.c_void_p, C.c_int]
     L.cafe_set_profiling.restype = C.c_int
     L.cafe_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.cafe_set_graphs.restype = C.c_int
+    L.cafe_set_graphs.argtypes = [C.c_void_p, C.c_int]
     L.cafe_comm_unique_id.restype = C.c_int
     L.cafe_comm_unique_id.argtypes = [C.c_char_p]
     L.cafe_comm_attach.restype = C.c_int
@@ -397,6 +400,10 @@ class Context:
 
     def set_profiling(self, on: bool):
         self._check(self._lib.cafe_set_profiling(self._h, 1 if on else 0))
+
+    def set_graphs(self, on: bool):
+        """False: enqueue every call launch by launch instead of replaying its captured hipGraph."""
+        self._check(self._lib.cafe_set_graphs(self._h, 1 if on else 0))
 
 
 class _Borrowed(Context):

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -27,6 +28,11 @@ struct Op {
     int src_child[2];
     int src_panels[2];
     bool to_root;
+    // gemm: the factor panel of the parent's OTHER interior child (fewer distinct columns than the parent), folded into
+    // this launch's epilogue through the parent->child column map
+    bool has_gath;
+    int gath_child;
+    int gath_panel;
 };
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -64,7 +70,19 @@ struct cafe_ctx {
     double* d_weights = nullptr;
     cafe::MatrixPool pool{nullptr, 0, 0, 0, 0, 0, 0};     // row-major matrices of leaf branches (K3)
     cafe::MatrixPool kpool{nullptr, 0, 0, 0, 0, 0, 1};    // k-major matrices of interior branches (K2)
+    // Matrix slots are static: one per (layout, distinct quantized branch length, lambda index) PAIR and category,
+    // slot = category * n_pairs[layout] + pair, so the slots of a call with K categories are a prefix of the pool and
+    // slot_of never changes.  (Two pairs whose lambda * multiplier happen to quantize alike are built twice.)
+    int n_pairs[2] = {0, 0};                 // [0] leaf branches (row-major pool), [1] interior branches (k-major pool)
+    std::vector<int> pair_of;                // [n_nodes] pair of the branch above a node (in its layout)
+    std::vector<long> pair_tq[2];            // quantized branch length of a pair (matrix_cache.h:47)
+    std::vector<int> pair_lam[2];            // lambda index of a pair
+    int n_distinct_pairs = 0;                // distinct (t_q, lambda index) over both layouts: matrices the reference would build per category
     int max_slots = 0, max_kslots = 0;
+    // per-call parameter block, one device allocation mirrored by the pinned h_stage (one upload per call):
+    // [SlotParam x max_slots][SlotParam x max_kslots][prior R][log prior R][category probabilities Kmax][error model]
+    char* d_params = nullptr;
+    size_t params_bytes = 0;
     cafe::SlotParam* d_slots = nullptr;                   // [max_slots] row-major, then [max_kslots] k-major
     double* d_panels = nullptr;
     int64_t panel_stride = 0;               // doubles per panel
@@ -100,8 +118,20 @@ struct cafe_ctx {
     int n_slots_last = 0, n_kslots_last = 0;
     int64_t last_chunk_f0 = 0, last_chunk_nf = 0;
 
+    // launch
+    int n_cu = 0;                            // compute units of the device (K2's persistent grid)
+    long stamps_launch = -1;                 // CAFE_GEMM_STAMPS_LAUNCH, read once at cafe_create
+    // A call's enqueue sequence is fixed per (reduction, K): upload, K1, the schedule, K4.  It is captured once in a
+    // hipGraph and replayed (one launch call instead of ~40 to ~300); the stream path remains for profiling runs.
+    struct CallGraph {
+        hipGraphExec_t exec = nullptr;
+        cafe_stats stats{};                  // the work counters of the captured sequence
+    };
+    std::map<int, CallGraph> graphs;
+    int use_graph = 1;
+
     // measurement
-    int profile = 1;
+    int profile = 0;
     int force_mi = 0;                        // diagnostic: K2 row-tile height for every launch (0 = chosen per launch)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> gemm_ev;

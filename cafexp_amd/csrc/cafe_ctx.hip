@@ -82,9 +82,28 @@ int emit_node(cafe_ctx* c, int v, const std::vector<int>& need, PanelAlloc& pa) 
     const bool first_direct = !inner.empty() && (!c->subtree_dedup || c->edge_identity[inner[0]]);
     size_t fused = (!first_direct || leaves.empty() || (c->n_dev != 0 && c->n_dev != 3)) ? 0 : 1;
     std::vector<std::pair<int, int>> factors;             // (child, scratch panel) waiting to be assembled
+    auto is_direct = [&](int u) { return !c->subtree_dedup || c->edge_identity[u]; };
+    if (inner.size() == 2 && leaves.empty() && is_direct(inner[0]) != is_direct(inner[1])) {
+        // one child shares the parent's columns, the other has fewer: the smaller one's factor GEMM runs first over ITS
+        // columns, the other's GEMM then writes the parent's panel and multiplies the gathered factor in (the product
+        // of two numbers: the same bits whichever child comes first)
+        const int big = is_direct(inner[0]) ? inner[0] : inner[1], small = big == inner[0] ? inner[1] : inner[0];
+        const int scratch = pa.get();
+        Op f{};
+        f.type = 1; f.parent = v; f.src_panel = panel_of[small]; f.child = small; f.to_root = (v == c->root);
+        f.dst_panel = scratch; f.mode = 0; f.to_factor = true;
+        c->ops.push_back(f);
+        Op g{};
+        g.type = 1; g.parent = v; g.src_panel = panel_of[big]; g.child = big; g.to_root = (v == c->root);
+        g.dst_panel = dst; g.mode = 0; g.has_gath = true; g.gath_child = small; g.gath_panel = scratch;
+        c->ops.push_back(g);
+        pa.put(scratch);
+        for (int u : inner) pa.put(panel_of[u]);
+        return dst;
+    }
     for (size_t gi = 0; gi < inner.size(); ++gi) {   // child order of the reference (probability.cpp:205 walks _descendants in order)
         const int u = inner[gi];
-        const bool direct = !c->subtree_dedup || c->edge_identity[u];
+        const bool direct = is_direct(u);
         Op op{};
         op.type = 1;
         op.parent = v;
@@ -145,7 +164,10 @@ int compute_patterns(cafe_ctx* c, const cafe_problem* p, const std::vector<int64
     c->d_edge_map.assign(n, nullptr);
     c->d_leaf_cnt.assign(n, nullptr);
     c->leaf_rank.assign(n, 0);
-    // ---- 1. every interior node's own patterns, children first
+    // ---- 1. every interior node's own patterns, children first.  Patterns are numbered in the order of the node's
+    // HEAVY child's pattern numbers (the interior child with the most patterns; ties and cherries: first occurrence in
+    // family order), so that along the heavy path a parent's columns map to non-decreasing child columns: the
+    // gathers of the assemble passes and of K2's gathered-factor epilogue then read the big factor panel in order.
     std::vector<std::vector<int32_t>> pid(n);            // [interior node][distinct family] own pattern index
     std::vector<std::vector<int64_t>> rep(n);            // [interior node][own pattern] first distinct family showing it
     for (int v = 0; v < n; ++v) {
@@ -153,33 +175,46 @@ int compute_patterns(cafe_ctx* c, const cafe_problem* p, const std::vector<int64
         std::vector<int> inner, leaves;
         for (int u : c->children[v]) (c->leaf_taxon[u] < 0 ? inner : leaves).push_back(u);
         const size_t kw = inner.size() + leaves.size();
+        pid[v].resize(F);
+        if (v == c->root) {                              // the root keeps one column per family of the context (K4 reads them
+            rep[v].resize(F);                            // by family index), also when identical families were kept apart
+            for (int64_t f = 0; f < F; ++f) { pid[v][f] = (int32_t)f; rep[v][f] = f; }
+            continue;
+        }
         std::unordered_map<std::string, int32_t> seen;
         seen.reserve((size_t)F * 2);
-        pid[v].resize(F);
+        std::vector<int64_t> first;                      // raw pattern (first-occurrence number) -> first family
         std::vector<int32_t> key(kw);
         for (int64_t f = 0; f < F; ++f) {
-            if (v == c->root) {                          // the root keeps one column per family of the context (K4 reads them
-                pid[v][f] = (int32_t)f;                  // by family index), also when identical families were kept apart
-                rep[v].push_back(f);
-                continue;
-            }
             size_t k = 0;
             for (int u : inner) key[k++] = pid[u][f];
             for (int u : leaves) key[k++] = p->counts[uniq[f] * T + c->leaf_taxon[u]];
             std::string ks(reinterpret_cast<const char*>(key.data()), sizeof(int32_t) * kw);
             auto it = seen.find(ks);
             if (it == seen.end()) {
-                it = seen.emplace(std::move(ks), (int32_t)rep[v].size()).first;
-                rep[v].push_back(f);
+                it = seen.emplace(std::move(ks), (int32_t)first.size()).first;
+                first.push_back(f);
             }
             pid[v][f] = it->second;
         }
+        int heavy = -1;
+        for (int u : inner) if (heavy < 0 || rep[u].size() > rep[heavy].size()) heavy = u;
+        const size_t U = first.size();
+        std::vector<int32_t> order(U), renum(U);
+        for (size_t i = 0; i < U; ++i) order[i] = (int32_t)i;
+        if (heavy >= 0)
+            std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return pid[heavy][first[x]] < pid[heavy][first[y]]; });
+        rep[v].resize(U);
+        for (size_t i = 0; i < U; ++i) { renum[order[i]] = (int32_t)i; rep[v][i] = first[order[i]]; }
+        for (int64_t f = 0; f < F; ++f) pid[v][f] = renum[pid[v][f]];
     }
-    // ---- 2. column space of every interior node, parents first: its own patterns, or -- when all the interior
-    // children of a parent have nearly as many patterns as the parent has columns -- the parent's columns, which
-    // makes those edges direct (GEMM epilogue writes the parent's panel, no assemble pass).  A GEMM column costs about
-    // 6.7 times an assembled one (6.0 ms against 0.9 ms per 50 000 columns at the bench shape): inherit when the
-    // extra GEMM columns stay below 15 % of the parent's.
+    // ---- 2. column space of every interior node, parents first: its own patterns, or its parent's columns, which makes
+    // the edge direct (the GEMM's epilogue writes the parent's panel).  A GEMM column costs about 0.12 us, a column of an
+    // assemble pass 0.024 us (one factor + leaf) to 0.036 us (two factors) at the bench shape, so:
+    //  * all interior children inherit when together they add < 15 % GEMM columns (store / multiply epilogues, one leaf
+    //    sibling fused);
+    //  * of two interior children (no leaf sibling) the larger one inherits alone when it adds < 30 %: the smaller one
+    //    keeps its own columns and its factor is gathered in the larger one's epilogue -- no assemble pass either.
     std::vector<int> space(n, -1);
     space[c->root] = c->root;
     for (int v = n - 1; v >= 0; --v) {
@@ -192,6 +227,10 @@ int compute_patterns(cafe_ctx* c, const cafe_problem* p, const std::vector<int64
         for (int u : inner) extra += 1.0 - (double)rep[u].size() / Uv;
         const bool inherit = !inner.empty() && n_leaves <= 1 && extra < 0.15;
         for (int u : inner) space[u] = inherit ? space[v] : u;
+        if (!inherit && inner.size() == 2 && n_leaves == 0) {
+            const int big = rep[inner[0]].size() >= rep[inner[1]].size() ? inner[0] : inner[1];
+            if (1.0 - (double)rep[big].size() / Uv < 0.30) space[big] = space[v];
+        }
     }
     // ---- 3. tables
     for (int v = 0; v < n; ++v) {
@@ -210,11 +249,11 @@ int compute_patterns(cafe_ctx* c, const cafe_problem* p, const std::vector<int64
             HIP_TRY(c, hipMemcpy(c->d_leaf_cnt[v], tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         }
         for (int u : inner) {
-            // same space, or own patterns that happen to be as many as the parent's columns (first-occurrence numbering
-            // on both sides: same order): the child's columns ARE the parent's
-            if (space[u] == space[v] || (int64_t)rep[u].size() == U) { c->edge_identity[u] = 1; continue; }
+            if (space[u] == space[v]) { c->edge_identity[u] = 1; continue; }      // the child's columns ARE the parent's
             std::vector<int32_t> map((size_t)Up, 0);
-            for (int64_t u2 = 0; u2 < U; ++u2) map[u2] = pid[u][cols[u2]];
+            bool same = (int64_t)rep[u].size() == U;     // as many own patterns as the parent has columns, in the same order?
+            for (int64_t u2 = 0; u2 < U; ++u2) { map[u2] = pid[u][cols[u2]]; same = same && map[u2] == (int32_t)u2; }
+            if (same) { c->edge_identity[u] = 1; continue; }
             HIP_TRY(c, hipMalloc(&c->d_edge_map[u], map.size() * sizeof(int32_t)));
             HIP_TRY(c, hipMemcpy(c->d_edge_map[u], map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         }
@@ -233,8 +272,9 @@ void free_device(cafe_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     comm_release(c);
-    hipFree(c->d_counts); hipFree(c->d_weights); hipFree(c->pool.base); hipFree(c->kpool.base); hipFree(c->d_slots); hipFree(c->d_panels);
-    hipFree(c->d_prior); hipFree(c->d_logprior); hipFree(c->d_catprobs); hipFree(c->d_err);
+    for (auto& g : c->graphs) if (g.second.exec) hipGraphExecDestroy(g.second.exec);
+    c->graphs.clear();
+    hipFree(c->d_counts); hipFree(c->d_weights); hipFree(c->pool.base); hipFree(c->kpool.base); hipFree(c->d_params); hipFree(c->d_panels);
     hipFree(c->d_fam_out); hipFree(c->d_fam_lik); hipFree(c->d_cat_out); hipFree(c->d_failed);
     hipFree(c->d_scratch); hipFree(c->d_result); hipFree(c->d_stamps);
     for (auto ptr : c->d_edge_map) hipFree(ptr);
@@ -358,26 +398,49 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
         c->n_panels = pa.high;
     }
 
-    // matrix pools: one slot per (branch, category); distinct quantized keys share a slot per call.
+    // matrix pools: one slot per (distinct quantized branch length, lambda index) pair and category, per layout.
     // Leaf branches use row-major matrices (K3 gathers a column), interior branches k-major ones (K2's A).
-    int n_leaf_branches = 0, n_inner_branches = 0;
-    for (int v = 0; v < c->n_nodes; ++v) {
-        if (v == c->root) continue;
-        (c->leaf_taxon[v] >= 0 ? n_leaf_branches : n_inner_branches) += 1;
+    c->pair_of.assign(c->n_nodes, -1);
+    {
+        std::map<std::pair<long, int>, int> seen[2], any;
+        for (int v = 0; v < c->n_nodes; ++v) {
+            if (v == c->root) continue;
+            const int layout = c->leaf_taxon[v] >= 0 ? 0 : 1;
+            long lq, tq;
+            quantize(0.0, c->blen[v], &lq, &tq);
+            const auto key = std::make_pair(tq, c->lam_idx[v]);
+            auto it = seen[layout].find(key);
+            if (it == seen[layout].end()) {
+                it = seen[layout].emplace(key, (int)c->pair_tq[layout].size()).first;
+                c->pair_tq[layout].push_back(tq);
+                c->pair_lam[layout].push_back(c->lam_idx[v]);
+            }
+            c->pair_of[v] = it->second;
+            any.emplace(key, 0);
+        }
+        c->n_pairs[0] = (int)c->pair_tq[0].size();
+        c->n_pairs[1] = (int)c->pair_tq[1].size();
+        c->n_distinct_pairs = (int)any.size();
     }
     c->kc = round_up(c->M + 1, kBK);
     c->pool.n = c->N;
     c->pool.ld = round_up(c->N, 16);
     c->pool.stride = (int64_t)c->N * c->pool.ld;
-    c->max_slots = n_leaf_branches * c->Kmax;
+    c->max_slots = c->n_pairs[0] * c->Kmax;
     c->kpool.n = c->N;
     c->kpool.rows = c->kc;
     c->kpool.k_valid = c->M + 1;
     c->kpool.kmajor = 1;
     c->kpool.ld = round_up(c->N - 1, 16) + round_up(kMaxBM, 16) + 16;     // a row tile may start at any valid row
     c->kpool.stride = (int64_t)c->kc * c->kpool.ld;
-    c->max_kslots = n_inner_branches * c->Kmax;
-    const size_t pool_bytes = (size_t)c->max_slots * c->pool.stride * sizeof(double);
+    c->max_kslots = c->n_pairs[1] * c->Kmax;
+    c->slot_of.assign((size_t)c->n_nodes * c->Kmax, -1);
+    for (int v = 0; v < c->n_nodes; ++v) {
+        if (v == c->root) continue;
+        const int layout = c->leaf_taxon[v] >= 0 ? 0 : 1;
+        for (int k = 0; k < c->Kmax; ++k) c->slot_of[(size_t)v * c->Kmax + k] = k * c->n_pairs[layout] + c->pair_of[v];
+    }
+    const size_t pool_bytes = (size_t)std::max(1, c->max_slots) * c->pool.stride * sizeof(double);
     const size_t kpool_bytes = (size_t)std::max(1, c->max_kslots) * c->kpool.stride * sizeof(double);
     if (hipMalloc(&c->pool.base, pool_bytes) != hipSuccess || hipMalloc(&c->kpool.base, kpool_bytes) != hipSuccess) {
         set_err(c, "cafe_create: cannot allocate %.2f GB for %d transition matrices of order %d", (pool_bytes + kpool_bytes) / 1e9,
@@ -387,19 +450,39 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     // padding columns / rows of both layouts are never written by K1 and must read as 0
     HIP_TRY(c, hipMemset(c->pool.base, 0, pool_bytes));
     HIP_TRY(c, hipMemset(c->kpool.base, 0, kpool_bytes));
-    HIP_TRY(c, hipMalloc(&c->d_slots, sizeof(SlotParam) * (c->max_slots + c->max_kslots)));
     c->stats.matrix_bytes = (int64_t)(pool_bytes + kpool_bytes);
 
-    // per-call parameter block
-    HIP_TRY(c, hipMalloc(&c->d_prior, sizeof(double) * c->R));
-    HIP_TRY(c, hipMalloc(&c->d_logprior, sizeof(double) * c->R));
-    HIP_TRY(c, hipMalloc(&c->d_catprobs, sizeof(double) * c->Kmax));
-    if (c->n_dev > 0) HIP_TRY(c, hipMalloc(&c->d_err, sizeof(double) * (size_t)(c->M + 1) * c->n_dev));
-    c->stage_bytes = sizeof(SlotParam) * (c->max_slots + c->max_kslots) + sizeof(double) * (2 * (size_t)c->R + c->Kmax + (size_t)(c->M + 1) * std::max(1, c->n_dev)) + 64;
-    HIP_TRY(c, hipHostMalloc(&c->h_stage, c->stage_bytes, hipHostMallocDefault));
+    // per-call parameter block (layout: cafe_ctx.h), device + pinned mirror
+    {
+        size_t off = sizeof(SlotParam) * (size_t)(c->max_slots + c->max_kslots);
+        off = (off + 63) / 64 * 64;
+        const size_t off_prior = off; off += sizeof(double) * c->R;
+        const size_t off_logprior = off; off += sizeof(double) * c->R;
+        const size_t off_cat = off; off += sizeof(double) * c->Kmax;
+        const size_t off_err = off; off += sizeof(double) * (size_t)(c->M + 1) * std::max(1, c->n_dev);
+        c->params_bytes = off;
+        HIP_TRY(c, hipMalloc(&c->d_params, c->params_bytes));
+        HIP_TRY(c, hipMemset(c->d_params, 0, c->params_bytes));
+        c->d_slots = reinterpret_cast<SlotParam*>(c->d_params);
+        c->d_prior = reinterpret_cast<double*>(c->d_params + off_prior);
+        c->d_logprior = reinterpret_cast<double*>(c->d_params + off_logprior);
+        c->d_catprobs = reinterpret_cast<double*>(c->d_params + off_cat);
+        c->d_err = c->n_dev > 0 ? reinterpret_cast<double*>(c->d_params + off_err) : nullptr;
+        c->stage_bytes = c->params_bytes;
+        HIP_TRY(c, hipHostMalloc(&c->h_stage, c->stage_bytes, hipHostMallocDefault));
+        std::memset(c->h_stage, 0, c->stage_bytes);
+    }
     HIP_TRY(c, hipHostMalloc(&c->h_result, 2 * sizeof(double), hipHostMallocDefault));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
     for (auto& e : c->ev) HIP_TRY(c, hipEventCreate(&e));
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+        c->n_cu = prop.multiProcessorCount;
+        const char* sl = std::getenv("CAFE_GEMM_STAMPS_LAUNCH");       // diagnostics: read once, never on the call path
+        c->stamps_launch = sl ? std::atol(sl) : -1;
+        if (std::getenv("CAFE_NO_GRAPH")) c->use_graph = 0;
+    }
 
     // outputs
     HIP_TRY(c, hipMalloc(&c->d_fam_out, sizeof(double) * c->Fp));
@@ -450,10 +533,14 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     c->stats.n_chunks = (c->Fp + c->chunk_cols - 1) / c->chunk_cols;
 
     int n_gemm = 0;
-    for (auto& op : c->ops) n_gemm += op.type == 1;
+    for (auto& op : c->ops) {
+        n_gemm += op.type == 1;
+        c->stats.n_gather_epilogues += op.type == 1 && op.has_gath;
+        c->stats.n_assemble_passes += op.type == 0 && op.n_src > 0;
+        c->stats.n_leaf_passes += op.type == 0 && op.n_src == 0;
+    }
     c->gemm_ev.resize((size_t)2 * n_gemm * c->stats.n_chunks);
     for (auto& e : c->gemm_ev) HIP_TRY(c, hipEventCreate(&e));
-    c->slot_of.assign((size_t)c->n_nodes * c->Kmax, -1);
     HIP_TRY(c, hipDeviceSynchronize());
     return CAFE_OK;
 }
@@ -468,27 +555,17 @@ bool lambdas_valid(const cafe_ctx* c, const double* lam) {
     return true;
 }
 
-// matrix keys: one slot per distinct (lambda_q, t_q) and layout; de-quantized like matrix_cache.cpp:148-149
-int prepare_matrices(cafe_ctx* c, const double* lambdas, const double* multipliers, int K, hipStream_t s) {
-    SlotParam* h_slots = reinterpret_cast<SlotParam*>(c->h_stage);
-    SlotParam* h_kslots = h_slots + c->max_slots;
-    std::map<std::pair<long, long>, int> key_slot[2];
-    int n_slots = 0, n_kslots = 0;
-    for (int v = 0; v < c->n_nodes; ++v) {
-        if (v == c->root) continue;
-        const int layout = c->leaf_taxon[v] >= 0 ? 0 : 1;
+// Slot parameters of a call into the pinned stage: slot = k * n_pairs[layout] + pair, built from the de-quantized key
+// like matrix_cache.cpp:148-149 (lambda.h:39, :82-88 for lambda * multiplier).
+void fill_slots(cafe_ctx* c, const double* lambdas, const double* multipliers, int K) {
+    SlotParam* h[2] = {reinterpret_cast<SlotParam*>(c->h_stage), reinterpret_cast<SlotParam*>(c->h_stage) + c->max_slots};
+    for (int layout = 0; layout < 2; ++layout) {
+        const int P = c->n_pairs[layout];
         for (int k = 0; k < K; ++k) {
             const double mult = multipliers ? multipliers[k] : 1.0;
-            const double lam = lambdas[c->lam_idx[v]] * mult;                   // lambda.h:39, :82-88
-            long lq, tq;
-            quantize(lam, c->blen[v], &lq, &tq);
-            auto key = std::make_pair(tq, lq);
-            auto it = key_slot[layout].find(key);
-            int slot;
-            if (it == key_slot[layout].end()) {
-                slot = layout ? n_kslots++ : n_slots++;
-                key_slot[layout].emplace(key, slot);
-                const double lambda_q = double(lq) / 1000000000.0, t_q = double(tq) / 1000.0;
+            for (int p = 0; p < P; ++p) {
+                const long lq = long(lambdas[c->pair_lam[layout][p]] * mult * 1000000000);     // matrix_cache.h:47
+                const double lambda_q = double(lq) / 1000000000.0, t_q = double(c->pair_tq[layout][p]) / 1000.0;
                 const double alpha = lambda_q * t_q / (1 + lambda_q * t_q);
                 const double coeff = 1 - 2 * alpha;
                 SlotParam sp;
@@ -496,21 +573,25 @@ int prepare_matrices(cafe_ctx* c, const double* lambdas, const double* multiplie
                 sp.oma2 = (1 - alpha) * (1 - alpha);
                 sp.zero = !(coeff > 0 && coeff != 1);       // saturated (coeff < 0) or degenerate: rows s>=1 are 0
                 sp.pad = 0;
-                (layout ? h_kslots : h_slots)[slot] = sp;
-            } else {
-                slot = it->second;
+                h[layout][k * P + p] = sp;
             }
-            c->slot_of[(size_t)v * c->Kmax + k] = slot;
         }
     }
-    c->n_slots_last = n_slots;
-    c->n_kslots_last = n_kslots;
-    c->stats.n_matrices = n_slots + n_kslots;
-    if (n_slots) HIP_TRY(c, hipMemcpyAsync(c->d_slots, h_slots, sizeof(SlotParam) * n_slots, hipMemcpyHostToDevice, s));
-    if (n_kslots) HIP_TRY(c, hipMemcpyAsync(c->d_slots + c->max_slots, h_kslots, sizeof(SlotParam) * n_kslots, hipMemcpyHostToDevice, s));
-    if (c->profile) HIP_TRY(c, hipEventRecord(c->ev[0], s));
-    HIP_TRY(c, launch_bd_matrix_build_both(c->pool, c->kpool, c->d_slots, c->d_slots + c->max_slots, n_slots, n_kslots, s));
-    if (c->profile) HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    c->n_slots_last = K * c->n_pairs[0];
+    c->n_kslots_last = K * c->n_pairs[1];
+    c->stats.n_matrices = (int64_t)K * c->n_distinct_pairs;
+}
+
+// For the callers outside the scorer path (reconstruct.hip): slot parameters uploaded on `s`, K1 launched.  Afterwards
+// slot_of[node * Kmax + k] (static) names the matrix of every branch and category.
+int prepare_matrices(cafe_ctx* c, const double* lambdas, const double* multipliers, int K, hipStream_t s) {
+    if (c->upload_pending) { HIP_TRY(c, hipEventSynchronize(c->ev_upload)); c->upload_pending = false; }
+    fill_slots(c, lambdas, multipliers, K);
+    const size_t nb = sizeof(SlotParam) * (size_t)(c->max_slots + c->max_kslots);
+    HIP_TRY(c, hipMemcpyAsync(c->d_params, c->h_stage, nb, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipEventRecord(c->ev_upload, s));
+    c->upload_pending = true;
+    HIP_TRY(c, launch_bd_matrix_build_both(c->pool, c->kpool, c->d_slots, c->d_slots + c->max_slots, c->n_slots_last, c->n_kslots_last, s));
     return CAFE_OK;
 }
 
@@ -538,70 +619,16 @@ bool rejected(const cafe_ctx* c, const cafe_params* pr, int K) {
     return (1 - 2 * alpha) < 0;
 }
 
-// rootmax: the p-value path (probability.cpp:273-317, 391-444) prunes with the plain lambda, no error model and
-// no prior, and keeps max_j L_root[j] per family instead of the scorer's reduction.
-int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bool rootmax = false) {
-    if (!pr || !pr->lambdas || (!rootmax && !pr->prior)) { set_err(c, "cafe_score: lambdas and prior are required"); return CAFE_ERR_ARGUMENT; }
-    const bool gamma = !rootmax && pr->model == CAFE_MODEL_GAMMA;
-    const bool use_err = !rootmax && c->n_dev > 0;
-    const int K = gamma ? pr->n_categories : 1;
-    if (gamma && (K < 1 || K > c->Kmax || !pr->multipliers || !pr->cat_probs)) {
-        set_err(c, "cafe_score: gamma model needs 1..%d categories with multipliers and cat_probs", c->Kmax);
-        return CAFE_ERR_ARGUMENT;
-    }
-    if (!rootmax && (c->n_dev > 0) != (pr->error_model != nullptr)) {
-        set_err(c, "cafe_score: error model %s but the problem was created with n_deviations=%d", pr->error_model ? "given" : "missing", c->n_dev);
-        return CAFE_ERR_ARGUMENT;
-    }
-    HIP_TRY(c, hipSetDevice(c->device));
-    c->last_stream = s;
-    if (c->upload_pending) { HIP_TRY(c, hipEventSynchronize(c->ev_upload)); c->upload_pending = false; }
-    c->have_results = false;
-    c->events_valid = false;
-    c->K_last = K;
-    c->model_last = rootmax ? CAFE_MODEL_BASE : pr->model;
-    c->rootmax_last = rootmax;
+// The device work of one call, enqueued on `s` (or recorded into a graph being captured on `s`): parameter upload,
+// K1, the schedule (K2 / K3 launches), K4, the final sum into d_out.  Everything that changes between calls of the
+// same shape travels through the parameter block; kernel arguments depend only on (reduction, K, error model).
+int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, double* d_out, hipStream_t s, bool events) {
     c->stats.gemm_flops = c->stats.gemm_bytes = c->stats.gemm_flops_per_family = 0;
     c->stats.gemm_launches = 0;
-
-    c->last_rejected = rootmax ? !lambdas_valid(c, pr->lambdas) : rejected(c, pr, K);
-    if (c->last_rejected) {
-        double* hr = reinterpret_cast<double*>(c->h_stage);
-        hr[0] = 0.0; hr[1] = 1.0;
-        HIP_TRY(c, hipMemcpyAsync(d_out, hr, 2 * sizeof(double), hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipEventRecord(c->ev_upload, s));
-        c->upload_pending = true;
-        c->stats.n_matrices = 0;
-        return CAFE_OK;
-    }
-
-    {
-        const int rc = prepare_matrices(c, pr->lambdas, gamma ? pr->multipliers : nullptr, K, s);
-        if (rc != CAFE_OK) return rc;
-    }
-    char* st = c->h_stage;
-    size_t off = sizeof(SlotParam) * (size_t)(c->max_slots + c->max_kslots);
-    double* h_prior = reinterpret_cast<double*>(st + off); off += sizeof(double) * c->R;
-    double* h_logprior = reinterpret_cast<double*>(st + off); off += sizeof(double) * c->R;
-    double* h_cat = reinterpret_cast<double*>(st + off); off += sizeof(double) * c->Kmax;
-    double* h_err = reinterpret_cast<double*>(st + off);
-    for (int j = 0; j < c->R; ++j) {
-        const double eq = rootmax ? 1.0 : (double)pr->prior[j];    // compute() returns float (root_equilibrium_distribution.h:15)
-        h_prior[j] = eq;
-        h_logprior[j] = std::log(eq);
-    }
-    for (int k = 0; k < K; ++k) h_cat[k] = gamma ? pr->cat_probs[k] : 1.0;
-    HIP_TRY(c, hipMemcpyAsync(c->d_prior, h_prior, sizeof(double) * c->R, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->d_logprior, h_logprior, sizeof(double) * c->R, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->d_catprobs, h_cat, sizeof(double) * K, hipMemcpyHostToDevice, s));
-    if (use_err) {
-        const size_t nb = sizeof(double) * (size_t)(c->M + 1) * c->n_dev;
-        std::memcpy(h_err, pr->error_model, nb);
-        HIP_TRY(c, hipMemcpyAsync(c->d_err, h_err, nb, hipMemcpyHostToDevice, s));
-    }
-    HIP_TRY(c, hipEventRecord(c->ev_upload, s));
-    c->upload_pending = true;
-
+    HIP_TRY(c, hipMemcpyAsync(c->d_params, c->h_stage, c->params_bytes, hipMemcpyHostToDevice, s));
+    if (events) HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    HIP_TRY(c, launch_bd_matrix_build_both(c->pool, c->kpool, c->d_slots, c->d_slots + c->max_slots, c->n_slots_last, c->n_kslots_last, s));
+    if (events) HIP_TRY(c, hipEventRecord(c->ev[1], s));
 
     // ---- prune, chunk by chunk
     c->gemm_ev_used = 0;
@@ -650,8 +677,7 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bo
                 g.mi = c->force_mi;                         // 0: launch_prune_gemm picks the tile height for this launch
                 g.n_row_tiles = g.mi ? (g.rows + 16 * g.mi - 1) / (16 * g.mi) : 0;
                 g.n_col_tiles = (int)(gc / kBN);
-                { const char* sl = std::getenv("CAFE_GEMM_STAMPS_LAUNCH"); const long want = sl ? std::atol(sl) : -1;
-                  g.stamps = (want < 0 || want == (long)c->stats.gemm_launches) ? c->d_stamps : nullptr; }
+                g.stamps = (c->stamps_launch < 0 || c->stamps_launch == (long)c->stats.gemm_launches) ? c->d_stamps : nullptr;
                 g.lpool = c->pool;
                 g.n_leaf = op.n_leaf;
                 for (int l = 0; l < op.n_leaf; ++l) {
@@ -660,16 +686,21 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bo
                 }
                 g.counts = cnt_base; g.counts_ld = cnt_ld; g.f0 = cnt_f0;
                 g.err = use_err ? c->d_err : nullptr; g.n_dev = use_err ? c->n_dev : 0; g.max_family_size = c->M;
-                if (c->profile && c->gemm_ev_used + 2 <= c->gemm_ev.size()) HIP_TRY(c, hipEventRecord(c->gemm_ev[c->gemm_ev_used++], s));
-                HIP_TRY(c, launch_prune_gemm(g, K, s));
-                if (c->profile && c->gemm_ev_used + 1 <= c->gemm_ev.size()) HIP_TRY(c, hipEventRecord(c->gemm_ev[c->gemm_ev_used++], s));
+                if (op.has_gath) {
+                    g.gath_src = c->d_panels + (int64_t)op.gath_panel * c->panel_stride;
+                    g.gath_ld = cols_of(op.gath_child);
+                    g.gath_map = c->d_edge_map[op.gath_child];
+                }
+                if (events && c->gemm_ev_used + 2 <= c->gemm_ev.size()) HIP_TRY(c, hipEventRecord(c->gemm_ev[c->gemm_ev_used++], s));
+                HIP_TRY(c, launch_prune_gemm(g, K, c->n_cu, s));
+                if (events && c->gemm_ev_used + 1 <= c->gemm_ev.size()) HIP_TRY(c, hipEventRecord(c->gemm_ev[c->gemm_ev_used++], s));
                 c->stats.gemm_launches += 1;
                 c->stats.gemm_flops += 2.0 * rows * (c->M + 1) * (double)gc * K;
                 c->stats.gemm_flops_per_family += 2.0 * rows * (c->M + 1) * (double)cols * K;
                 c->stats.gemm_bytes += 8.0 * K * ((double)rows * (c->M + 1) + (double)(c->M + 1) * gc + (double)rows * gc);
             }
         }
-        if (c->profile && f0 + c->chunk_cols >= c->Fp) HIP_TRY(c, hipEventRecord(c->ev[2], s));
+        if (events && f0 + c->chunk_cols >= c->Fp) HIP_TRY(c, hipEventRecord(c->ev[2], s));
         ReduceArgs r{};
         r.root = c->d_panels + (int64_t)c->root_panel * c->panel_stride;
         r.panel_kstride = c->panel_kstride; r.ld = (int)cols; r.R = c->R; r.K = K; r.model = rootmax ? 2 : (gamma ? 1 : 0);
@@ -681,7 +712,93 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bo
         c->last_chunk_nf = r.nf;
     }
     HIP_TRY(c, launch_final_sum(c->d_fam_out, c->d_weights, c->d_failed, c->F_uniq, c->d_scratch, c->n_scratch, d_out, s));
-    if (c->profile) { HIP_TRY(c, hipEventRecord(c->ev[3], s)); c->events_valid = true; }
+    if (events) { HIP_TRY(c, hipEventRecord(c->ev[3], s)); c->events_valid = true; }
+    return CAFE_OK;
+}
+
+// rootmax: the p-value path (probability.cpp:273-317, 391-444) prunes with the plain lambda, no error model and
+// no prior, and keeps max_j L_root[j] per family instead of the scorer's reduction.
+int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bool rootmax = false) {
+    if (!pr || !pr->lambdas || (!rootmax && !pr->prior)) { set_err(c, "cafe_score: lambdas and prior are required"); return CAFE_ERR_ARGUMENT; }
+    const bool gamma = !rootmax && pr->model == CAFE_MODEL_GAMMA;
+    const bool use_err = !rootmax && c->n_dev > 0;
+    const int K = gamma ? pr->n_categories : 1;
+    if (gamma && (K < 1 || K > c->Kmax || !pr->multipliers || !pr->cat_probs)) {
+        set_err(c, "cafe_score: gamma model needs 1..%d categories with multipliers and cat_probs", c->Kmax);
+        return CAFE_ERR_ARGUMENT;
+    }
+    if (!rootmax && (c->n_dev > 0) != (pr->error_model != nullptr)) {
+        set_err(c, "cafe_score: error model %s but the problem was created with n_deviations=%d", pr->error_model ? "given" : "missing", c->n_dev);
+        return CAFE_ERR_ARGUMENT;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->last_stream = s;
+    if (c->upload_pending) { HIP_TRY(c, hipEventSynchronize(c->ev_upload)); c->upload_pending = false; }
+    c->have_results = false;
+    c->events_valid = false;
+    c->K_last = K;
+    c->model_last = rootmax ? CAFE_MODEL_BASE : pr->model;
+    c->rootmax_last = rootmax;
+
+    c->last_rejected = rootmax ? !lambdas_valid(c, pr->lambdas) : rejected(c, pr, K);
+    if (c->last_rejected) {
+        double* hr = reinterpret_cast<double*>(c->h_stage);
+        hr[0] = 0.0; hr[1] = 1.0;
+        HIP_TRY(c, hipMemcpyAsync(d_out, hr, 2 * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipEventRecord(c->ev_upload, s));
+        c->upload_pending = true;
+        c->stats.n_matrices = 0;
+        c->stats.gemm_flops = c->stats.gemm_bytes = c->stats.gemm_flops_per_family = 0;
+        c->stats.gemm_launches = 0;
+        return CAFE_OK;
+    }
+
+    // ---- the call's parameters into the pinned mirror of the device block
+    fill_slots(c, pr->lambdas, gamma ? pr->multipliers : nullptr, K);
+    {
+        double* h_prior = reinterpret_cast<double*>(c->h_stage + ((char*)c->d_prior - c->d_params));
+        double* h_logprior = reinterpret_cast<double*>(c->h_stage + ((char*)c->d_logprior - c->d_params));
+        double* h_cat = reinterpret_cast<double*>(c->h_stage + ((char*)c->d_catprobs - c->d_params));
+        for (int j = 0; j < c->R; ++j) {
+            const double eq = rootmax ? 1.0 : (double)pr->prior[j];    // compute() returns float (root_equilibrium_distribution.h:15)
+            h_prior[j] = eq;
+            h_logprior[j] = std::log(eq);
+        }
+        for (int k = 0; k < K; ++k) h_cat[k] = gamma ? pr->cat_probs[k] : 1.0;
+        if (use_err) std::memcpy(c->h_stage + ((char*)c->d_err - c->d_params), pr->error_model, sizeof(double) * (size_t)(c->M + 1) * c->n_dev);
+    }
+
+    const bool graph_ok = c->use_graph && !c->profile && !c->d_stamps && c->force_mi == 0;
+    if (!graph_ok) {
+        const int rc = record_call(c, K, gamma, rootmax, use_err, d_out, s, c->profile != 0);
+        if (rc != CAFE_OK) return rc;
+    } else {
+        const int key = (rootmax ? 2 : (gamma ? 1 : 0)) + 4 * K;
+        cafe_ctx::CallGraph& cg = c->graphs[key];
+        if (!cg.exec) {
+            // capture on the context's own stream (idle: calls are sequential), replay on the caller's
+            hipGraph_t graph = nullptr;
+            HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            const int rc = record_call(c, K, gamma, rootmax, use_err, c->d_result, c->stream, false);
+            const hipError_t ee = hipStreamEndCapture(c->stream, &graph);
+            if (rc != CAFE_OK) { if (graph) (void)hipGraphDestroy(graph); c->graphs.erase(key); return rc; }
+            if (ee != hipSuccess || !graph) { c->graphs.erase(key); set_err(c, "hipStreamEndCapture failed: %s", hipGetErrorString(ee)); return CAFE_ERR_DEVICE; }
+            const hipError_t ei = hipGraphInstantiate(&cg.exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ei != hipSuccess) { c->graphs.erase(key); set_err(c, "hipGraphInstantiate failed: %s", hipGetErrorString(ei)); return CAFE_ERR_DEVICE; }
+            cg.stats = c->stats;
+        }
+        const int64_t n_mat = c->stats.n_matrices;
+        c->stats.gemm_flops = cg.stats.gemm_flops; c->stats.gemm_bytes = cg.stats.gemm_bytes;
+        c->stats.gemm_flops_per_family = cg.stats.gemm_flops_per_family; c->stats.gemm_launches = cg.stats.gemm_launches;
+        c->stats.n_matrices = n_mat;
+        c->last_chunk_f0 = (c->Fp - 1) / c->chunk_cols * c->chunk_cols;
+        c->last_chunk_nf = std::max<int64_t>(0, std::min<int64_t>(c->chunk_cols, c->F_uniq - c->last_chunk_f0));
+        HIP_TRY(c, hipGraphLaunch(cg.exec, s));
+        if (d_out != c->d_result) HIP_TRY(c, hipMemcpyAsync(d_out, c->d_result, 2 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_upload, s));
+    c->upload_pending = true;
     c->have_results = true;
     return CAFE_OK;
 }
@@ -912,6 +1029,12 @@ int cafe_debug_force_tile(cafe_ctx* ctx, int mi) {
 int cafe_set_profiling(cafe_ctx* ctx, int on) {
     if (!ctx) return CAFE_ERR_ARGUMENT;
     ctx->profile = on ? 1 : 0;
+    return CAFE_OK;
+}
+
+int cafe_set_graphs(cafe_ctx* ctx, int on) {
+    if (!ctx) return CAFE_ERR_ARGUMENT;
+    ctx->use_graph = on ? 1 : 0;
     return CAFE_OK;
 }
 

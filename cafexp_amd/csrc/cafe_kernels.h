@@ -73,6 +73,11 @@ struct GemmArgs {
     const double* err;              // [(M+1)][n_dev] or nullptr
     int32_t n_dev;
     int32_t max_family_size;
+    // factor panel of an interior sibling with fewer distinct columns than the parent, folded into the epilogue:
+    // column f of the parent takes column gath_map[f] of gath_src (same category layout as the panels)
+    const double* gath_src;
+    int64_t gath_ld;
+    const int32_t* gath_map;
 };
 
 struct GatherArgs {
@@ -122,7 +127,7 @@ struct ReduceArgs {
 hipError_t launch_bd_matrix_build(const MatrixPool& pool, const SlotParam* d_slots, int n_slots, hipStream_t stream);
 hipError_t launch_bd_matrix_build_both(const MatrixPool& pool, const MatrixPool& kpool, const SlotParam* d_slots, const SlotParam* d_kslots,
                                        int n_slots, int n_kslots, hipStream_t stream);
-hipError_t launch_prune_gemm(const GemmArgs& a, int n_categories, hipStream_t stream);
+hipError_t launch_prune_gemm(const GemmArgs& a, int n_categories, int n_cu, hipStream_t stream);   // n_cu: compute units of the stream's device
 int prune_gemm_pick_mi(int rows, int n_col_tiles, int n_categories, int slots);     // row-tile height (in 16-row blocks)
 hipError_t launch_leaf_gather(const GatherArgs& a, int n_categories, hipStream_t stream);
 hipError_t launch_root_reduce(const ReduceArgs& a, hipStream_t stream);

@@ -43,8 +43,11 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 [[maybe_unused]] constexpr int kBStride = kBN + 16;                        // 144 doubles
 constexpr int a_stride(int bm) { return (bm % 32 == 16) ? bm : bm + 16; }
 
-// MI: row tile = 16*MI.  MUL: multiply into the parent panel instead of storing.  LEAF (0, 1 or 3 = taps): one leaf
-// sibling (no error model) is folded into the epilogue.
+// MI: row tile = 16*MI.  MUL: multiply into the parent panel instead of storing.  LEAF: what else the epilogue folds in --
+// 1 or 3 (= taps): one leaf sibling (its factor is a gathered column of its matrix, or the three error-model taps);
+// 2: the factor panel of an interior sibling that has fewer distinct columns than the parent, gathered through the
+// parent->sibling column map (subtree-level de-duplication): the parent's panel is then complete after this launch,
+// without an assemble pass.
 template <int MI, bool MUL, int LEAF>
 __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the body uses amdgcn-only types (buffer resource); hipcc's host pass only needs the stub
@@ -58,7 +61,8 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: LDS-DMA bases (M0) need no VALU
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int lda = a.pool.ld, ldb = a.ld, ldl = a.lpool.ld;
+    constexpr bool GATH = LEAF == 2;
+    const int lda = a.pool.ld, ldb = a.ld, ldl = GATH ? (int)a.gath_ld : a.lpool.ld;   // ldl: row stride of what the epilogue gathers
     unsigned long long st0 = 0, ep_ticks = 0, n_done = 0;
     if (a.stamps) st0 = __builtin_amdgcn_s_memrealtime();
 
@@ -253,7 +257,17 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
         unsigned l_voff[2][NT];
         double l_w[2][NT];                                  // error-model weights (taps outside [0, M]: weight 0, clamped column)
         int l_soff0 = 0;
-        if (LEAF) {
+        if (GATH) {
+            // sibling factor F[s][map[column]]: the same access shape as a leaf's matrix column, another base and stride
+            const int32_t* mp = a.gath_map + cur.col0 + wave * 32 + l15;
+            rsL = __builtin_amdgcn_make_buffer_rsrc((void*)(a.gath_src + (int64_t)cur.cat * a.panel_kstride), 0, kbytes, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                l_voff[j][0] = (unsigned)((l4 * ldl + mp[16 * j]) * 8);
+                l_w[j][0] = 1.0;
+            }
+            l_soff0 = (cur.row0 + a.out_off) * ldl * 8;
+        } else if (LEAF) {
             const int32_t* cnt = a.counts + (int64_t)a.taxon[0] * a.counts_ld + a.f0 + cur.col0 + wave * 32 + l15;
             rsL = __builtin_amdgcn_make_buffer_rsrc((void*)(a.lpool.base + (int64_t)a.leaf_slot[0][cur.cat] * a.lpool.stride), 0,
                                                     (int)(a.lpool.stride * 8), 0x00020000);
@@ -282,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
                 for (int j = 0; j < 2; ++j) {
                     double f = 1.0;
                     if (ok) {
-                        if (LEAF == 1) f = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsL, l_voff[j][0], l_soff0 + step * ldl * 8, 0));
+                        if (LEAF == 1 || GATH) f = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsL, l_voff[j][0], l_soff0 + step * ldl * 8, 0));
                         if (LEAF == 3) {                // sum_i err[x][i] * P_leaf[s][x - 1 + i], taps in order (leaf_reduce.hip)
                             f = 0.0;
 #pragma unroll
@@ -338,7 +352,11 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
             const int c2 = tid * 2;
             const double* Bp = a.src + (int64_t)cur.cat * a.panel_kstride + cur.col0 + c2;
             double2 v = *reinterpret_cast<const double2*>(Bp);
-            if (LEAF) {
+            if (GATH) {                                     // the sibling's factor at parent size 0
+                const double* G = a.gath_src + (int64_t)cur.cat * a.panel_kstride;
+                v.x *= G[a.gath_map[cur.col0 + c2]];
+                v.y *= G[a.gath_map[cur.col0 + c2 + 1]];
+            } else if (LEAF) {
                 const int32_t* cnt = a.counts + (int64_t)a.taxon[0] * a.counts_ld + a.f0 + cur.col0 + c2;
                 if (LEAF == 1) {
                     v.x = cnt[0] == 0 ? v.x : 0.0;
@@ -390,7 +408,11 @@ int prune_gemm_pick_mi(int rows, int n_col_tiles, int n_categories, int slots) {
 template <int MI>
 static void launch_mi(const GemmArgs& a, dim3 grid, hipStream_t stream) {
     const dim3 block(256);
-    const int leaf = a.n_leaf ? (a.err ? 3 : 1) : 0;
+    const int leaf = a.n_leaf ? (a.err ? 3 : 1) : (a.gath_src ? 2 : 0);
+    if (leaf == 2) {                                       // gathered sibling factor: always the launch that creates the panel
+        hipLaunchKernelGGL((prune_gemm_kernel<MI, false, 2>), grid, block, 0, stream, a);
+        return;
+    }
     if (a.mode) {
         if (leaf == 3) hipLaunchKernelGGL((prune_gemm_kernel<MI, true, 3>), grid, block, 0, stream, a);
         else if (leaf == 1) hipLaunchKernelGGL((prune_gemm_kernel<MI, true, 1>), grid, block, 0, stream, a);
@@ -402,19 +424,14 @@ static void launch_mi(const GemmArgs& a, dim3 grid, hipStream_t stream) {
     }
 }
 
-hipError_t launch_prune_gemm(const GemmArgs& a_in, int n_categories, hipStream_t stream) {
+hipError_t launch_prune_gemm(const GemmArgs& a_in, int n_categories, int n_cu, hipStream_t stream) {
     if (a_in.n_leaf > 1 || (a_in.n_leaf == 1 && a_in.err != nullptr && a_in.n_dev != 3)) return hipErrorInvalidValue;   // the schedule never asks for it
+    if (a_in.gath_src && (a_in.n_leaf || a_in.mode || !a_in.gath_map)) return hipErrorInvalidValue;
     GemmArgs a = a_in;
     a.n_categories = n_categories;
     // persistent grid: two workgroups per CU (what the register/LDS budget admits), a multiple of 8 so that every
     // XCD gets the same number; fewer when the launch has fewer tiles
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
-        n_cu = prop.multiProcessorCount;
-    }
+    if (n_cu < 8) return hipErrorInvalidValue;
     int blocks = 2 * n_cu / 8 * 8;
     if (a.mi == 0) {                                       // the caller leaves the tile height to the launcher
         a.mi = prune_gemm_pick_mi(a.rows, a.n_col_tiles, n_categories, blocks);

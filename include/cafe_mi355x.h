@@ -126,6 +126,10 @@ typedef struct cafe_stats {
     int64_t n_chunks;
     int64_t matrix_bytes;
     int64_t panel_bytes;
+    /* the schedule (fixed at cafe_create): */
+    int64_t n_assemble_passes;       /* K3 launches that spread factor panels of de-duplicated children over a parent's columns */
+    int64_t n_gather_epilogues;      /* K2 launches that fold a sibling's factor panel into their epilogue instead */
+    int64_t n_leaf_passes;           /* K3 launches with leaf children only (cherries, polytomies, error models) */
 } cafe_stats;
 
 /* NULL on failure; err (optional, errlen bytes) receives the reason. */
@@ -224,8 +228,12 @@ int cafe_get_matrix(cafe_ctx* ctx, int32_t node, int32_t category, double* out, 
 int cafe_get_root_likelihoods(cafe_ctx* ctx, int64_t family, int32_t category, double* out, size_t out_len);
 int cafe_get_stats(const cafe_ctx* ctx, cafe_stats* stats);
 int cafe_matrix_size(const cafe_ctx* ctx);
-/* 1 (default): bracket every K2 launch with HIP events so that cafe_stats.ms_gemm is measured; 0: off. */
+/* 1: bracket the phases and every K2 launch with HIP events so that cafe_stats.ms_* are measured (bench.py does); such
+ * calls are enqueued launch by launch.  0 (default): no events, and the call's fixed launch sequence is captured once
+ * per (model, K) in a hipGraph and replayed. */
 int cafe_set_profiling(cafe_ctx* ctx, int on);
+/* 0: never use hipGraphs (also: environment CAFE_NO_GRAPH at cafe_create); 1 (default): as described above. */
+int cafe_set_graphs(cafe_ctx* ctx, int on);
 /* diagnostic: K2's row tile is 16*mi rows, mi = 4..9, normally chosen per launch; mi forces one, 0 restores the choice */
 int cafe_debug_force_tile(cafe_ctx* ctx, int mi);
 /* diagnostic (CAFE_GEMM_STAMPS=1 at cafe_create): per-block placement + timeline words of the last K2 launch */

@@ -1,8 +1,13 @@
-"""The N > 1 path on CPU: two gloo ranks shard the families exactly like bench.py, each produces the pair
-{sum lnL, rejects} for its shard, one all-reduce (gloo here, RCCL on the GPUs) combines them, and the
-result equals the single-process score.  There is no GPU in this container, so the per-shard pair comes
-from the CPU oracle -- it stands in for cafe_score_partial's output; the sharding, the reduction and
-cafe_finish_partial's rule are the code under test."""
+"""The N > 1 path on CPU.
+
+(1) cafe_shard_plan -- the library's own family partition (host code of libcafe_mi355x.so, no GPU needed): a
+    partition, deterministic, balanced by distinct subtree patterns.
+(2) Two gloo ranks shard the families with that plan exactly like bench.py, each produces the pair {sum lnL, rejects}
+    for its shard, one all-reduce (gloo here; on the GPUs the library's own ncclAllReduce inside cafe_score) combines
+    them, the library's cafe_finish_partial turns the pair into the scorer value, and the result equals the
+    single-process score.  There is no GPU in this container, so the per-shard pair comes from the CPU oracle -- it
+    stands in for cafe_score_partial's output; the plan, the reduction and cafe_finish_partial are the code under test.
+"""
 import math
 import os
 import sys
@@ -16,15 +21,57 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _finish(pair):            # cafe_finish_partial (cafexp_amd/csrc/cafe_ctx.hip)
-    return math.inf if pair[1] > 0 else -pair[0]
+def _distinct_columns(pb, fams, tile=1):
+    """Distinct leaf-count patterns under every interior non-root node (padded to the device's column tile), summed: the
+    device's unit of work."""
+    C = np.ascontiguousarray(pb.counts[fams])
+    n = pb.n_nodes
+    children = [[] for _ in range(n)]
+    for v in range(n):
+        if pb.parent[v] >= 0:
+            children[int(pb.parent[v])].append(v)
+    leafset = [None] * n
+    total = 0
+    for v in range(n):
+        leafset[v] = [int(pb.leaf_taxon[v])] if pb.leaf_taxon[v] >= 0 else [t for c in children[v] for t in leafset[c]]
+        if pb.leaf_taxon[v] < 0 and pb.parent[v] >= 0:
+            total += -(-len(np.unique(C[:, leafset[v]], axis=0)) // tile) * tile
+    return total
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_shard_plan_is_a_balanced_partition(world):
+    sys.path.insert(0, ROOT)
+    from cafexp_amd import capi, synth
+    pb, _ = synth.make_problem(n_taxa=24, n_families=4000, max_count=80, lam_sim=0.004, seed=5, root_cap=50)
+    plan = capi.shard_plan(pb, world)
+    again = capi.shard_plan(pb, world)
+    assert len(plan) == world
+    assert all(len(p) > 0 for p in plan)
+    assert np.array_equal(np.sort(np.concatenate(plan)), np.arange(pb.n_families))      # every family exactly once
+    assert all(np.array_equal(a, b) for a, b in zip(plan, again))                        # every rank derives the same plan
+    if world > 1:
+        cost = np.array([_distinct_columns(pb, p, tile=128) for p in plan], dtype=float)   # K2's tiles are 128 columns wide
+        assert cost.max() / cost.min() < 1.12, cost                                       # by distinct patterns, not family count
+        assert max(len(p) for p in plan) > min(len(p) for p in plan)                      # ... which is not an even family count
+        # look-alikes share a shard: the shards together hold fewer distinct columns than contiguous blocks of the table
+        blocks = np.array_split(np.arange(pb.n_families), world)
+        assert cost.sum() < sum(_distinct_columns(pb, b) for b in blocks)
+
+
+def test_shard_plan_rejects_more_shards_than_families():
+    sys.path.insert(0, ROOT)
+    from cafexp_amd import capi, synth
+    pb, _ = synth.make_problem(n_taxa=6, n_families=5, max_count=20, lam_sim=0.004, seed=2, root_cap=10)
+    with pytest.raises(capi.CafeError):
+        capi.shard_plan(pb, 6)
 
 
 def _worker(rank, world, port, case, out):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import dataclasses
-    from cafexp_amd import problem as P, synth
+    from cafexp_amd import capi, problem as P, synth
     from oracle import oracle as O
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -37,14 +84,18 @@ def _worker(rank, world, port, case, out):
         pr = P.Params(lambdas=np.array([-0.1]), prior=P.prior_uniform(pb.max_root_family_size))
     else:
         pr = P.Params(lambdas=np.array([0.004]), prior=P.prior_uniform(pb.max_root_family_size))
-    lo, hi = P.shard_families(pb.n_families, world, rank)
-    shard = dataclasses.replace(pb, counts=np.ascontiguousarray(pb.counts[lo:hi]), family_ids=pb.family_ids[lo:hi])
+    mine = capi.shard_plan(pb, world)[rank]                 # bench.py's sharding: the library's plan
+    shard = dataclasses.replace(pb, counts=np.ascontiguousarray(pb.counts[mine]), family_ids=[pb.family_ids[i] for i in mine])
     v = O.score(shard, pr)
     pair = torch.tensor([0.0, 1.0] if math.isinf(v) else [-v, 0.0], dtype=torch.float64)
     dist.all_reduce(pair)
     if rank == 0:
         whole = O.score(pb, pr)
-        out.put((_finish(pair.tolist()), whole, hi - lo))
+        lib = capi.load()
+        a = np.ascontiguousarray(pair.numpy(), dtype=np.float64)
+        import ctypes
+        got = lib.cafe_finish_partial(a.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))     # the library's own rule
+        out.put((got, whole, len(mine)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -65,3 +116,32 @@ def test_two_rank_shards_allreduce_to_the_whole(case):
         assert got == whole == math.inf
     else:
         assert abs(got - whole) / whole < 1e-13
+
+
+def test_bench_parent_starts_its_ranks_without_touching_the_gpu():
+    """`python bench.py --gpus N` run plainly must launch N ranks itself (the driver invokes it that way) and must do so
+    before importing torch / touching the GPU: checked on the launcher function's command line."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    import subprocess
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_run(cmd, **kw):
+        seen["cmd"] = cmd
+        class R:
+            returncode = 0
+            stdout = '{"metric": "x", "n_gpus": 4}\\n'
+        return R()
+    real = subprocess.run
+    subprocess.run = fake_run
+    try:
+        args = type("A", (), {"gpus": 4})()
+        before = "torch" in sys.modules and hasattr(sys.modules["torch"], "_bench_marker")
+        rc = bench.launch_ranks(args)
+    finally:
+        subprocess.run = real
+    assert rc == 0 and not before
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert "127.0.0.1" in cmd and os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"

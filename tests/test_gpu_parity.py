@@ -11,7 +11,7 @@ import math
 import numpy as np
 import pytest
 
-from cafexp_amd import problem as P
+from cafexp_amd import problem as P, synth
 from helpers import case_from_args, rel_err
 
 pytestmark = pytest.mark.gpu
@@ -429,3 +429,89 @@ def test_partial_api_on_torch_stream(capi, oracle):
     assert rel_err(got, oracle.score_base(pb, pr)) <= SCORE_TOL
     ctx.score_partial(P.Params(lambdas=np.array([-1.0]), prior=P.prior_uniform(40)), buf.data_ptr(), stream.cuda_stream)
     assert ctx.finish(buf.cpu().numpy()) == math.inf
+
+
+# ------------------------------------------------------------------ round 2: graphs, gathered-factor epilogue, multi-GPU entry points
+@pytest.mark.parametrize("name", ["mammals_base_l0.01", "mammals_gamma_k4_a2", "mammals_multilambda_err"])
+def test_graph_replay_equals_stream_enqueue(capi, oracle, golden, name):
+    """A call's launch sequence is captured once per (model, K) in a hipGraph and replayed; with graphs switched off (or
+    profiling on) the same sequence is enqueued launch by launch.  Same kernels, same arguments: the same bits -- also
+    when the parameters change between replays (they travel through the uploaded block, not through kernel arguments)."""
+    e = golden["scores"][name]
+    pb, pr, alpha = case_from_args(e["args"], oracle)
+    K = 0 if pr.multipliers is None else len(pr.multipliers)
+    g = capi.Context(pb, max_categories=max(1, K))
+    s = capi.Context(pb, max_categories=max(1, K))
+    s.set_graphs(False)
+    import dataclasses
+    for scale in (1.0, 0.5, 1.0, 1.7):
+        q = dataclasses.replace(pr, lambdas=pr.lambdas * scale)
+        vg, rg = g.score(q, alpha=alpha, per_family=True)
+        vs, rs = s.score(q, alpha=alpha, per_family=True)
+        assert vg == vs
+        for key in rg:
+            assert np.array_equal(rg[key], rs[key]), key
+    assert rel_err(g.score(pr, alpha=alpha), e["neg_lnl"]) <= SCORE_TOL
+    p = capi.Context(pb, max_categories=max(1, K))
+    p.set_profiling(True)
+    assert p.score(pr, alpha=alpha) == g.score(pr, alpha=alpha)
+    assert p.stats()["ms_prune"] > 0
+
+
+def test_gathered_factor_epilogue_is_used_and_bit_identical(capi, oracle):
+    """Two interior children of which only the larger shares the parent's columns: the smaller one's factor panel is
+    gathered in the larger one's GEMM epilogue (no assemble pass).  The schedule counters show it happened; the values
+    equal the one-column-per-family run to the last bit and the oracle to tolerance."""
+    rng = np.random.default_rng(5)
+    newick = "((((A:1,B:2):1,(C:1,D:1):2):1.5,(I:2,J:2):2):1,(((E:1,F:1):1,G:2):1,H:3):1);"      # gathers below the root and at it
+    tree = P.parse_newick(newick)
+    names = [l.name for l in tree.leaves()]
+    F = 3000
+    counts = 1 + (rng.random(size=(F, len(names))) < 0.08).astype(np.int64)     # E..J: nearly constant, few patterns
+    for nm in "ABCD":
+        counts[:, names.index(nm)] = rng.integers(0, 31, size=F)        # a rich clade (A..D): nearly one pattern per family
+    counts[0, names.index("A")] = 40
+    pb = P.build_problem(tree, names, ["f%d" % i for i in range(F)], counts, root_filter=True, max_family_size=60, max_root_family_size=50)
+    probs, mult = oracle.discrete_gamma(3, 1.2)
+    pr = P.Params(lambdas=np.array([0.02]), prior=P.prior_uniform(50), multipliers=mult, cat_probs=probs)
+    a = capi.Context(pb, max_categories=3)
+    b = capi.Context(pb, max_categories=3, subtree_dedup=False)
+    va, ra = a.score(pr, alpha=1.2, per_family=True)
+    vb, rb = b.score(pr, alpha=1.2, per_family=True)
+    st = a.stats()
+    assert st["n_gather_epilogues"] >= 2, st
+    assert b.stats()["n_gather_epilogues"] == 0 and b.stats()["n_assemble_passes"] == 0
+    assert va == vb
+    for key in ra:
+        assert np.array_equal(ra[key], rb[key]), key
+    sel = np.arange(0, pb.n_families, 97)
+    import dataclasses
+    sub = dataclasses.replace(pb, counts=pb.counts[sel].copy(), family_ids=[pb.family_ids[i] for i in sel])
+    _, cat, fam = oracle.score_gamma(sub, pr, per_family=True)
+    assert np.max(np.abs(ra["family_likelihood"][sel] / fam - 1)) <= 1e-11
+    # the base model through the same schedule
+    pr1 = P.Params(lambdas=np.array([0.02]), prior=P.prior_uniform(50))
+    assert a.score(pr1) == b.score(pr1)
+
+
+def test_sharded_scorer_on_one_device_and_comm_attach(capi, oracle):
+    """cafe_create_sharded / cafe_comm_attach with a world of one GPU: the whole multi-GPU machinery (plan, worker thread,
+    ncclCommInitAll / ncclCommInitRank, ncclAllReduce inside cafe_score, results gathered back into table order) on the
+    one device this box has."""
+    pb, _ = synth.make_problem(n_taxa=14, n_families=900, max_count=50, lam_sim=0.004, seed=9, root_cap=35)
+    probs, mult = oracle.discrete_gamma(3, 1.5)
+    pr = P.Params(lambdas=np.array([0.004]), prior=P.prior_uniform(pb.max_root_family_size), multipliers=mult, cat_probs=probs)
+    one = capi.Context(pb, max_categories=3)
+    v1, r1 = one.score(pr, alpha=1.5, per_family=True)
+    sh = capi.Sharded(pb, [0], max_categories=3)
+    assert sh.size == 1
+    v2, r2 = sh.score(pr, alpha=1.5, per_family=True)
+    assert rel_err(v2, v1) <= 1e-14                       # another family order inside the shard: the sum's rounding only
+    for key in r1:
+        assert np.array_equal(r1[key], r2[key]), key      # per-family values: the same bits, back in table order
+    assert sh.score(P.Params(lambdas=np.array([-1.0]), prior=pr.prior)) == np.inf
+    sh.close()
+    one.comm_attach(capi.comm_unique_id(), 1, 0)
+    assert one.score(pr, alpha=1.5) == v1
+    one.comm_detach()
+    assert one.score(pr, alpha=1.5) == v1
