@@ -88,6 +88,7 @@ struct cafe_ctx {
     int64_t panel_stride = 0;               // doubles per panel
     int64_t panel_kstride = 0;              // doubles per category inside a panel
     int rows_pad = 0, kc = 0;
+    int factor_ld = 0;                       // rows per column of a transposed factor panel
     int64_t chunk_cols = 0;
     size_t workspace_limit = 0;             // cafe_problem::workspace_limit (0 = automatic)
     double *d_prior = nullptr, *d_logprior = nullptr, *d_catprobs = nullptr, *d_err = nullptr;

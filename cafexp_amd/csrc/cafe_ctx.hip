@@ -213,8 +213,9 @@ int compute_patterns(cafe_ctx* c, const cafe_problem* p, const std::vector<int64
     // assemble pass 0.024 us (one factor + leaf) to 0.036 us (two factors) at the bench shape, so:
     //  * all interior children inherit when together they add < 15 % GEMM columns (store / multiply epilogues, one leaf
     //    sibling fused);
-    //  * of two interior children (no leaf sibling) the larger one inherits alone when it adds < 30 %: the smaller one
-    //    keeps its own columns and its factor is gathered in the larger one's epilogue -- no assemble pass either.
+    //  * of two interior children (no leaf sibling) the larger one inherits alone when it adds < 12 % (an assemble pass
+    //    saved is worth about that many GEMM columns): the smaller one keeps its own columns and its factor is gathered
+    //    in the larger one's epilogue -- no assemble pass either.
     std::vector<int> space(n, -1);
     space[c->root] = c->root;
     for (int v = n - 1; v >= 0; --v) {
@@ -229,7 +230,7 @@ int compute_patterns(cafe_ctx* c, const cafe_problem* p, const std::vector<int64
         for (int u : inner) space[u] = inherit ? space[v] : u;
         if (!inherit && inner.size() == 2 && n_leaves == 0) {
             const int big = rep[inner[0]].size() >= rep[inner[1]].size() ? inner[0] : inner[1];
-            if (1.0 - (double)rep[big].size() / Uv < 0.30) space[big] = space[v];
+            if (1.0 - (double)rep[big].size() / Uv < 0.12) space[big] = space[v];
         }
     }
     // ---- 3. tables
@@ -499,7 +500,10 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     }
 
     // likelihood panels: rows padded so that every panel can be a GEMM B operand (kc rows) or the root (R rows)
-    c->rows_pad = std::max(c->kc, round_up(c->R, kBK));
+    // a factor GEMM stores transposed, [column][16 - out_off + panel row] (prune_gemm.hip): factor_ld rows per column, and a
+    // panel slot must be able to hold a factor of as many columns
+    c->factor_ld = round_up(std::max(c->M + 1, c->R) + 16, 16);
+    c->rows_pad = std::max(std::max(c->kc, round_up(c->R, kBK)), c->factor_ld);
     size_t free_b = 0, total_b = 0;
     HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
     c->workspace_limit = p->workspace_limit;
@@ -521,7 +525,8 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     }
     c->panel_kstride = (int64_t)c->rows_pad * c->chunk_cols;
     c->panel_stride = c->panel_kstride * c->Kmax;
-    const size_t panel_bytes = (size_t)c->n_panels * c->panel_stride * sizeof(double);
+    // (+64 KB: the assemble pass reads whole 64-row tiles of a transposed factor, up to a tile past its last column)
+    const size_t panel_bytes = (size_t)c->n_panels * c->panel_stride * sizeof(double) + 65536;
     if (hipMalloc(&c->d_panels, panel_bytes) != hipSuccess) {
         set_err(c, "cafe_create: cannot allocate %.2f GB of likelihood panels", panel_bytes / 1e9);
         return CAFE_ERR_MEMORY;
@@ -660,7 +665,7 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
                 g.n_src = op.n_src;
                 for (int j = 0; j < op.n_src; ++j) {
                     g.src[j] = c->d_panels + (int64_t)op.src_panels[j] * c->panel_stride;
-                    g.ld_src[j] = cols_of(op.src_child[j]);
+                    g.ld_src[j] = c->factor_ld;
                     g.map[j] = c->d_edge_map[op.src_child[j]];
                 }
                 HIP_TRY(c, launch_leaf_gather(g, K, s));
@@ -674,6 +679,7 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
                 g.rows = op.to_root ? c->R : c->M;           // parent sizes 1..rows
                 g.out_off = op.to_root ? 0 : 1;
                 g.mode = op.mode;
+                g.dst_ldt = op.to_factor ? c->factor_ld : 0;
                 g.mi = c->force_mi;                         // 0: launch_prune_gemm picks the tile height for this launch
                 g.n_row_tiles = g.mi ? (g.rows + 16 * g.mi - 1) / (16 * g.mi) : 0;
                 g.n_col_tiles = (int)(gc / kBN);
@@ -688,7 +694,7 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
                 g.err = use_err ? c->d_err : nullptr; g.n_dev = use_err ? c->n_dev : 0; g.max_family_size = c->M;
                 if (op.has_gath) {
                     g.gath_src = c->d_panels + (int64_t)op.gath_panel * c->panel_stride;
-                    g.gath_ld = cols_of(op.gath_child);
+                    g.gath_ld = c->factor_ld;
                     g.gath_map = c->d_edge_map[op.gath_child];
                 }
                 if (events && c->gemm_ev_used + 2 <= c->gemm_ev.size()) HIP_TRY(c, hipEventRecord(c->gemm_ev[c->gemm_ev_used++], s));

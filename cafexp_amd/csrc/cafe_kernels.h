@@ -74,10 +74,13 @@ struct GemmArgs {
     int32_t n_dev;
     int32_t max_family_size;
     // factor panel of an interior sibling with fewer distinct columns than the parent, folded into the epilogue:
-    // column f of the parent takes column gath_map[f] of gath_src (same category layout as the panels)
+    // column f of the parent takes column gath_map[f] of the TRANSPOSED factor gath_src (kFactorLd rows per column)
     const double* gath_src;
     int64_t gath_ld;
     const int32_t* gath_map;
+    // > 0: this launch is a factor GEMM and stores transposed, dst[column][16 - out_off + panel row], dst_ldt rows per
+    // column (see prune_gemm.hip)
+    int32_t dst_ldt;
 };
 
 struct GatherArgs {
@@ -99,7 +102,8 @@ struct GatherArgs {
     int32_t n_dev;
     int32_t max_family_size;        // M
     // factor panels of interior children that have fewer distinct columns than this parent (subtree-level
-    // de-duplication): column f of the parent takes column map[j][f] of factor j
+    // de-duplication): column f of the parent takes column map[j][f] of factor j.  Factors are stored TRANSPOSED by
+    // their GEMM (prune_gemm.hip, TRANS): src[j][category][column][15 + row_off + panel row], ld_src rows per column.
     int32_t n_src;
     const double* src[2];
     int64_t ld_src[2];

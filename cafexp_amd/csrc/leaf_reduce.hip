@@ -61,8 +61,8 @@ __global__ __launch_bounds__(256) void leaf_gather_kernel(const GatherArgs a) {
                     v *= fac;
                 }
             }
-            for (int j = 0; j < a.n_src; ++j)
-                v *= a.src[j][(int64_t)cat * a.panel_kstride + (int64_t)r * a.ld_src[j] + a.map[j][f]];
+            for (int j = 0; j < a.n_src; ++j)           // transposed factors: [column][15 + row_off + panel row]
+                v *= a.src[j][(int64_t)cat * a.panel_kstride + (int64_t)a.map[j][f] * a.ld_src[j] + 15 + a.row_off + r];
             if (a.mode) v *= dst[(int64_t)r * a.ld];
         }
         dst[(int64_t)r * a.ld] = v;
@@ -164,16 +164,114 @@ static void launch_fast3(const GatherArgs& a, dim3 grid, hipStream_t stream) {
 }
 template <int NLEAF, int NDEV>
 static void launch_fast(const GatherArgs& a, dim3 grid, hipStream_t stream) {
-    if (a.n_src == 0) { if (NLEAF > 0) launch_fast3<(NLEAF > 0 ? NLEAF : 1), NDEV, 0>(a, grid, stream); }
-    else if (a.n_src == 1) launch_fast3<NLEAF, NDEV, 1>(a, grid, stream);
-    else launch_fast3<NLEAF, NDEV, 2>(a, grid, stream);
+    launch_fast3<NLEAF, NDEV, 0>(a, grid, stream);
+}
+
+// Assemble pass: the parent's panel from the TRANSPOSED factor panels of its de-duplicated interior children (and its
+// leaf children): P[r][c] = prod_j F_j[map_j[c]][r] * prod_leaves P_leaf[r][x_leaf(c)].  A factor column is contiguous
+// along the rows, so a workgroup fetches, per mapped column, whole 128-byte lines (32 lanes x 16 bytes per column and
+// instruction), multiplies the factors in that orientation, turns the 64 x 64 tile through LDS and writes the panel rows
+// 512 contiguous bytes per wave instruction.  Bound: HBM (factors read once, panel written once); the row-major gather
+// this replaces issued one 8-byte element per 128-byte line and was bound by the texture addresser (3.8 TB/s of L2
+// traffic, profiles/r01).
+constexpr int kAsmT = 64;                   // tile: 64 columns x 64 rows of the transposed index space
+constexpr int kAsmS = kAsmT + 1;            // LDS row stride (doubles): column-wise reads of a row-major tile without conflicts
+template <int NSRC, int NLEAF, int NDEV, bool MUL>
+__global__ __launch_bounds__(256) void assemble_t_kernel(const GatherArgs a) {
+    __shared__ double tile[kAsmT * kAsmS];
+    const int cat = blockIdx.z;
+    const int c0 = blockIdx.x * kAsmT;                       // first parent column of the tile (ld is a multiple of 128)
+    const int i0 = blockIdx.y * kAsmT;                       // first transposed row index: panel row = index - toff
+    const int toff = 15 + a.row_off;
+    const int tid = threadIdx.x;
+    // ---- phase A: 64 columns x 64 indices of each factor, 16 bytes per lane, 32 lanes per column
+    {
+        const int seg = tid & 31, cl = tid >> 5;             // column cl + 8 * i of the tile
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = cl + 8 * i;
+            double2 v = make_double2(1.0, 1.0);
+#pragma unroll
+            for (int j = 0; j < NSRC; ++j) {
+                const double2 f = *reinterpret_cast<const double2*>(a.src[j] + (int64_t)cat * a.panel_kstride +
+                                                                    (int64_t)a.map[j][c0 + c] * a.ld_src[j] + i0 + 2 * seg);
+                v.x *= f.x;
+                v.y *= f.y;
+            }
+            tile[c * kAsmS + 2 * seg] = v.x;
+            tile[c * kAsmS + 2 * seg + 1] = v.y;
+        }
+    }
+    __syncthreads();
+    // ---- phase B: wave w writes panel rows (indices) i0 + 16 w .. + 15, lane = column
+    const int lane = tid & 63, w = tid >> 6;
+    const int f = c0 + lane;
+    constexpr int NL = NLEAF > 0 ? NLEAF : 1;
+    constexpr int half = (NDEV - 1) / 2;
+    unsigned o[NL][NDEV];
+    double wgt[NL][NDEV];
+    const double* P[NL];
+#pragma unroll
+    for (int l = 0; l < NLEAF; ++l) {
+        const int x = a.counts[(int64_t)a.taxon[l] * a.counts_ld + a.f0 + f];
+#pragma unroll
+        for (int i = 0; i < NDEV; ++i) {
+            const int c = x - half + i;
+            const bool ok = c >= 0 && c <= a.max_family_size;
+            o[l][i] = (unsigned)(ok ? c : x);
+            wgt[l][i] = NDEV == 1 ? 1.0 : (ok ? a.err[(int64_t)x * NDEV + i] : 0.0);
+        }
+        P[l] = a.pool.base + (int64_t)a.slot[l][cat] * a.pool.stride;
+    }
+    double* __restrict__ dst = a.dst + (int64_t)cat * a.panel_kstride + f;
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = i0 + 16 * w + rr - toff;               // panel row
+        if (r < 0 || r >= a.rows_store) continue;
+        double v = 0.0;
+        if (r < a.rows) {
+            v = tile[lane * kAsmS + 16 * w + rr];
+#pragma unroll
+            for (int l = 0; l < NLEAF; ++l) {
+                const double* row = P[l] + (int64_t)(r + a.row_off) * a.pool.ld;
+                if (NDEV == 1) {
+                    v *= row[o[l][0]];
+                } else {
+                    double fx = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NDEV; ++i) fx += row[o[l][i]] * wgt[l][i];
+                    v *= fx;
+                }
+            }
+            if (MUL) v *= dst[(int64_t)r * a.ld];
+        }
+        __builtin_nontemporal_store(v, dst + (int64_t)r * a.ld);
+    }
+}
+
+template <int NSRC, int NLEAF, int NDEV>
+static void launch_asm3(const GatherArgs& a, dim3 grid, hipStream_t stream) {
+    if (a.mode) hipLaunchKernelGGL((assemble_t_kernel<NSRC, NLEAF, NDEV, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((assemble_t_kernel<NSRC, NLEAF, NDEV, false>), grid, dim3(256), 0, stream, a);
+}
+template <int NSRC>
+static void launch_asm(const GatherArgs& a, int ndev, dim3 grid, hipStream_t stream) {
+    if (a.n_leaf == 0) launch_asm3<NSRC, 0, 1>(a, grid, stream);
+    else if (a.n_leaf == 1) { if (ndev == 1) launch_asm3<NSRC, 1, 1>(a, grid, stream); else launch_asm3<NSRC, 1, 3>(a, grid, stream); }
+    else { if (ndev == 1) launch_asm3<NSRC, 2, 1>(a, grid, stream); else launch_asm3<NSRC, 2, 3>(a, grid, stream); }
 }
 
 hipError_t launch_leaf_gather(const GatherArgs& a, int n_categories, hipStream_t stream) {
     (void)hipGetLastError();
     if (a.n_leaf == 0 && a.n_src == 0) return hipErrorInvalidValue;
     const int ndev = a.err == nullptr ? 1 : a.n_dev;
-    if ((ndev == 1 || ndev == 3) && a.n_leaf <= 2 && a.n_src <= 2) {
+    if ((ndev == 1 || ndev == 3) && a.n_leaf <= 2 && a.n_src >= 1 && a.n_src <= 2) {
+        dim3 grid(a.ld / kAsmT, (a.rows_store + 15 + a.row_off + kAsmT - 1) / kAsmT, n_categories);
+        if (a.n_src == 1) launch_asm<1>(a, ndev, grid, stream);
+        else launch_asm<2>(a, ndev, grid, stream);
+        return hipGetLastError();
+    }
+    if ((ndev == 1 || ndev == 3) && a.n_leaf <= 2 && a.n_src == 0) {
         dim3 grid((a.ld / 2 + 255) / 256, (a.rows_store + kFastRows - 1) / kFastRows, n_categories);
         if (a.n_leaf == 0) launch_fast<0, 1>(a, grid, stream);
         else if (a.n_leaf == 1) { if (ndev == 1) launch_fast<1, 1>(a, grid, stream); else launch_fast<1, 3>(a, grid, stream); }

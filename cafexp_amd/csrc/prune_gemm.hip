@@ -47,8 +47,11 @@ constexpr int a_stride(int bm) { return (bm % 32 == 16) ? bm : bm + 16; }
 // 1 or 3 (= taps): one leaf sibling (its factor is a gathered column of its matrix, or the three error-model taps);
 // 2: the factor panel of an interior sibling that has fewer distinct columns than the parent, gathered through the
 // parent->sibling column map (subtree-level de-duplication): the parent's panel is then complete after this launch,
-// without an assemble pass.
-template <int MI, bool MUL, int LEAF>
+// without an assemble pass.  TRANS: a factor GEMM (plain store over the CHILD's columns) writes its result transposed,
+// F_T[column][16 - out_off + panel row] with the rows contiguous: whoever spreads that factor over the parent's columns
+// (K3's assemble pass, the LEAF == 2 epilogue) then fetches whole 128-byte lines per mapped column instead of one
+// 8-byte element per line.  The +16 puts every 16-row block of the tile on a line boundary.
+template <int MI, bool MUL, int LEAF, bool TRANS = false>
 __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the body uses amdgcn-only types (buffer resource); hipcc's host pass only needs the stub
     constexpr int BM = 16 * MI;
@@ -62,7 +65,8 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: LDS-DMA bases (M0) need no VALU
     const int l15 = lane & 15, l4 = lane >> 4;
     constexpr bool GATH = LEAF == 2;
-    const int lda = a.pool.ld, ldb = a.ld, ldl = GATH ? (int)a.gath_ld : a.lpool.ld;   // ldl: row stride of what the epilogue gathers
+    const int lda = a.pool.ld, ldb = a.ld, ldl = GATH ? (int)a.gath_ld : a.lpool.ld;   // ldl: stride of what the epilogue gathers
+    const int ldt = a.dst_ldt;                                     // TRANS: rows per column of the transposed factor
     unsigned long long st0 = 0, ep_ticks = 0, n_done = 0;
     if (a.stamps) st0 = __builtin_amdgcn_s_memrealtime();
 
@@ -250,8 +254,8 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
         // All accesses are buffer operations: descriptor + SCALAR offset (row block, register row group, column
         // half) + one fixed per-lane offset -- no address VALU and no LDS round trip; the old panel values (MUL) and
         // the leaf factors (LEAF) of row block i+1 are loaded before block i is stored.
-        const unsigned c_voff = (unsigned)((l4 * ldb + wave * 32 + l15) * 8);
-        const int c_soff0 = ((cur.row0 + a.out_off) * ldb + cur.col0) * 8;
+        const unsigned c_voff = TRANS ? (unsigned)(((wave * 32 + l15) * ldt + l4) * 8) : (unsigned)((l4 * ldb + wave * 32 + l15) * 8);
+        const int c_soff0 = TRANS ? (cur.col0 * ldt + cur.row0 + 16) * 8 : ((cur.row0 + a.out_off) * ldb + cur.col0) * 8;
         __amdgpu_buffer_rsrc_t rsL = cur.rsC;
         constexpr int NT = LEAF == 3 ? 3 : 1;               // taps of the leaf sibling: 1, or the 3 of an error model
         unsigned l_voff[2][NT];
@@ -263,10 +267,10 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
             rsL = __builtin_amdgcn_make_buffer_rsrc((void*)(a.gath_src + (int64_t)cur.cat * a.panel_kstride), 0, kbytes, 0x00020000);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                l_voff[j][0] = (unsigned)((l4 * ldl + mp[16 * j]) * 8);
+                l_voff[j][0] = (unsigned)((mp[16 * j] * ldl + l4) * 8);     // transposed factor: [column][16 - out_off + row]
                 l_w[j][0] = 1.0;
             }
-            l_soff0 = (cur.row0 + a.out_off) * ldl * 8;
+            l_soff0 = (cur.row0 + 16) * 8;
         } else if (LEAF) {
             const int32_t* cnt = a.counts + (int64_t)a.taxon[0] * a.counts_ld + a.f0 + cur.col0 + wave * 32 + l15;
             rsL = __builtin_amdgcn_make_buffer_rsrc((void*)(a.lpool.base + (int64_t)a.leaf_slot[0][cur.cat] * a.lpool.stride), 0,
@@ -296,7 +300,8 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
                 for (int j = 0; j < 2; ++j) {
                     double f = 1.0;
                     if (ok) {
-                        if (LEAF == 1 || GATH) f = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsL, l_voff[j][0], l_soff0 + step * ldl * 8, 0));
+                        if (LEAF == 1) f = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsL, l_voff[j][0], l_soff0 + step * ldl * 8, 0));
+                        if (GATH) f = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsL, l_voff[j][0], l_soff0 + step * 8, 0));
                         if (LEAF == 3) {                // sum_i err[x][i] * P_leaf[s][x - 1 + i], taps in order (leaf_reduce.hip)
                             f = 0.0;
 #pragma unroll
@@ -319,7 +324,8 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
                     for (int j = 0; j < 2; ++j) {
                         double v = acc[i][j][r];
                         if (MUL || LEAF) v *= p.f[j][r];
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(int2_t, v), cur.rsC, c_voff, c_soff0 + (step * ldb + j * 16) * 8, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(int2_t, v), cur.rsC, c_voff,
+                                                              c_soff0 + (TRANS ? (j * 16 * ldt + step) * 8 : (step * ldb + j * 16) * 8), 0);
                     }
                 }
             }
@@ -352,10 +358,10 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
             const int c2 = tid * 2;
             const double* Bp = a.src + (int64_t)cur.cat * a.panel_kstride + cur.col0 + c2;
             double2 v = *reinterpret_cast<const double2*>(Bp);
-            if (GATH) {                                     // the sibling's factor at parent size 0
-                const double* G = a.gath_src + (int64_t)cur.cat * a.panel_kstride;
-                v.x *= G[a.gath_map[cur.col0 + c2]];
-                v.y *= G[a.gath_map[cur.col0 + c2 + 1]];
+            if (GATH) {                                     // the sibling's factor at parent size 0 (transposed: row index 15)
+                const double* G = a.gath_src + (int64_t)cur.cat * a.panel_kstride + 15;
+                v.x *= G[(int64_t)a.gath_map[cur.col0 + c2] * ldl];
+                v.y *= G[(int64_t)a.gath_map[cur.col0 + c2 + 1] * ldl];
             } else if (LEAF) {
                 const int32_t* cnt = a.counts + (int64_t)a.taxon[0] * a.counts_ld + a.f0 + cur.col0 + c2;
                 if (LEAF == 1) {
@@ -366,13 +372,19 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
                     v.y *= cnt[1] == 0 ? a.err[1] : (cnt[1] == 1 ? a.err[3] : 0.0);
                 }
             }
-            double2* dst = reinterpret_cast<double2*>(a.dst + (int64_t)cur.cat * a.panel_kstride + cur.col0 + c2);
-            if (MUL) {
-                const double2 old = *dst;
-                v.x *= old.x;
-                v.y *= old.y;
+            if (TRANS) {
+                double* dt = a.dst + (int64_t)cur.cat * a.panel_kstride + (int64_t)(cur.col0 + c2) * ldt + 15;
+                dt[0] = v.x;
+                dt[ldt] = v.y;
+            } else {
+                double2* dst = reinterpret_cast<double2*>(a.dst + (int64_t)cur.cat * a.panel_kstride + cur.col0 + c2);
+                if (MUL) {
+                    const double2 old = *dst;
+                    v.x *= old.x;
+                    v.y *= old.y;
+                }
+                *dst = v;
             }
-            *dst = v;
         }
         // the stores need no wait here (they drain during the next main loop)
     }
@@ -413,6 +425,10 @@ static void launch_mi(const GemmArgs& a, dim3 grid, hipStream_t stream) {
         hipLaunchKernelGGL((prune_gemm_kernel<MI, false, 2>), grid, block, 0, stream, a);
         return;
     }
+    if (a.dst_ldt) {                                       // factor GEMM: transposed plain store
+        hipLaunchKernelGGL((prune_gemm_kernel<MI, false, 0, true>), grid, block, 0, stream, a);
+        return;
+    }
     if (a.mode) {
         if (leaf == 3) hipLaunchKernelGGL((prune_gemm_kernel<MI, true, 3>), grid, block, 0, stream, a);
         else if (leaf == 1) hipLaunchKernelGGL((prune_gemm_kernel<MI, true, 1>), grid, block, 0, stream, a);
@@ -426,7 +442,8 @@ static void launch_mi(const GemmArgs& a, dim3 grid, hipStream_t stream) {
 
 hipError_t launch_prune_gemm(const GemmArgs& a_in, int n_categories, int n_cu, hipStream_t stream) {
     if (a_in.n_leaf > 1 || (a_in.n_leaf == 1 && a_in.err != nullptr && a_in.n_dev != 3)) return hipErrorInvalidValue;   // the schedule never asks for it
-    if (a_in.gath_src && (a_in.n_leaf || a_in.mode || !a_in.gath_map)) return hipErrorInvalidValue;
+    if (a_in.gath_src && (a_in.n_leaf || a_in.mode || !a_in.gath_map || a_in.dst_ldt)) return hipErrorInvalidValue;
+    if (a_in.dst_ldt && (a_in.n_leaf || a_in.mode)) return hipErrorInvalidValue;
     GemmArgs a = a_in;
     a.n_categories = n_categories;
     // persistent grid: two workgroups per CU (what the register/LDS budget admits), a multiple of 8 so that every

@@ -296,7 +296,7 @@ def test_chunked_workspace_equals_single_chunk(capi, oracle):
     probs, mult = oracle.discrete_gamma(2, 2.0)
     pr = P.Params(lambdas=np.array([0.01]), prior=P.prior_uniform(50), multipliers=mult, cat_probs=probs)
     one = capi.Context(pb, max_categories=2)
-    many = capi.Context(pb, max_categories=2, workspace_limit=3 * 2 * 64 * 8 * 256 + 1)   # room for 256 columns -> 3 chunks
+    many = capi.Context(pb, max_categories=2, workspace_limit=6 * 2 * 80 * 8 * 256 + 1)   # room for 256 columns (6 panels x 2 categories x 80 rows) -> 3 chunks
     v1, r1 = one.score(pr, alpha=2.0, per_family=True)
     v2, r2 = many.score(pr, alpha=2.0, per_family=True)
     assert many.stats()["n_chunks"] >= 3 and one.stats()["n_chunks"] == 1
@@ -446,9 +446,11 @@ def test_graph_replay_equals_stream_enqueue(capi, oracle, golden, name):
     import dataclasses
     for scale in (1.0, 0.5, 1.0, 1.7):
         q = dataclasses.replace(pr, lambdas=pr.lambdas * scale)
-        vg, rg = g.score(q, alpha=alpha, per_family=True)
-        vs, rs = s.score(q, alpha=alpha, per_family=True)
+        vg, vs = g.score(q, alpha=alpha), s.score(q, alpha=alpha)
         assert vg == vs
+        if math.isinf(vg) and scale != 1.0:
+            continue                                      # rejected on the host (saturation): no per-family results
+        rg, rs = g.family_results(K), s.family_results(K)
         for key in rg:
             assert np.array_equal(rg[key], rs[key]), key
     assert rel_err(g.score(pr, alpha=alpha), e["neg_lnl"]) <= SCORE_TOL
