@@ -236,9 +236,9 @@ def main():
         # every rank derives the same plan; shards are balanced by predicted device time (distinct subtree patterns)
         if args.emulate_shard:
             er, ew = (int(x) for x in args.emulate_shard.split("/"))
-            mine = capi.shard_plan(pb, ew)[er]
+            mine = capi.shard_plan(pb, ew, max(1, K))[er]
         elif world > 1:
-            mine = capi.shard_plan(pb, world)[rank]
+            mine = capi.shard_plan(pb, world, max(1, K))[rank]
         else:
             mine = np.arange(F)
         shard = pb if len(mine) == F and world == 1 else dataclasses.replace(

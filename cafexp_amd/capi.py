@@ -216,11 +216,11 @@ def _c_params(pr: Params, alpha: float = 1.0):
     return cp, keep
 
 
-def shard_plan(pb: Problem, n_shards: int):
+def shard_plan(pb: Problem, n_shards: int, max_categories: int = 1):
     """cafe_shard_plan: the library's balanced family partition (host code, no GPU needed).
     Returns the family indices of every shard (a list of n_shards int64 arrays)."""
     keep = []
-    cp = _c_problem(pb, keep)
+    cp = _c_problem(pb, keep, max_categories)
     order = np.empty(pb.n_families, dtype=np.int64)
     bounds = np.empty(n_shards + 1, dtype=np.int64)
     rc = load().cafe_shard_plan(C.byref(cp), n_shards, order.ctypes.data_as(C.POINTER(C.c_int64)), bounds.ctypes.data_as(C.POINTER(C.c_int64)))

@@ -537,6 +537,18 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     c->stats.n_unique_families = c->F_uniq;
     c->stats.n_chunks = (c->Fp + c->chunk_cols - 1) / c->chunk_cols;
 
+    if (std::getenv("CAFE_DUMP_SCHEDULE")) {             // diagnostic: the launch list with its column counts
+        for (auto& op : c->ops) {
+            const int64_t pc = c->subtree_dedup ? c->pat_cols[op.parent] : c->chunk_cols;
+            if (op.type == 1)
+                std::fprintf(stderr, "cafe schedule: gemm child %d -> parent %d cols %lld %s%s%s leaf %d\n", op.child, op.parent,
+                             (long long)(c->subtree_dedup ? c->pat_cols[op.child] : c->chunk_cols), op.to_factor ? "factor(transposed)" : (op.mode ? "multiply" : "store"),
+                             op.has_gath ? " +gathered-factor" : "", op.to_root ? " root" : "", op.n_leaf);
+            else
+                std::fprintf(stderr, "cafe schedule: %s parent %d cols %lld factors %d leaves %d %s\n", op.n_src ? "assemble" : "leaf-gather", op.parent,
+                             (long long)pc, op.n_src, op.n_leaf, op.mode ? "multiply" : "store");
+        }
+    }
     int n_gemm = 0;
     for (auto& op : c->ops) {
         n_gemm += op.type == 1;

@@ -76,7 +76,7 @@ struct ShardModel {
     std::vector<int64_t> order;                    // shard order -> family
     std::vector<int> nodes;                        // interior non-root nodes
     std::vector<std::vector<int64_t>> prev;        // [nodes.size()][F]
-    int rows_inner = 0, rows_root = 0;
+    int rows_inner = 0, rows_root = 0, categories = 1;
 };
 
 int build_shard_model(const cafe_problem* p, ShardModel& m) {
@@ -86,6 +86,7 @@ int build_shard_model(const cafe_problem* p, ShardModel& m) {
     const int64_t F = m.F = p->n_families;
     m.rows_inner = p->max_family_size + 1;
     m.rows_root = p->max_root_family_size;
+    m.categories = std::max(1, p->max_categories);
     // look-alikes next to each other: total size, then the rows lexicographically (stable: equal rows keep table order)
     std::vector<int64_t> total(F, 0);
     for (int64_t f = 0; f < F; ++f)
@@ -130,16 +131,41 @@ int build_shard_model(const cafe_problem* p, ShardModel& m) {
     return CAFE_OK;
 }
 
-// Predicted device time of the shard [a, b) in arbitrary units: per interior branch one GEMM over the node's distinct
-// columns (padded to the 128-column tile) -- 2*rows*(M+1) flop per column -- plus the gather/assemble traffic of the
-// parent's panel, both linear in the padded columns; the root's children run over one column per family.
+// Predicted device time (microseconds) of the shard [a, b): per interior branch one K2 launch over the node's distinct
+// columns, costed the way the launcher picks its row tile -- whole rounds of the persistent grid times the tile height
+// (prune_gemm_pick_mi; about 20 us per 16-row block of a round at two workgroups per CU, 17 us when the launch leaves the
+// CUs one workgroup each) -- plus the memory passes that write (and gather) the node's panel, about 8.4 ns per column
+// and panel touched at K = 8, M = 720 (two panels on average), plus a launch's fixed cost.  The round quantisation is the
+// point: at a 1/8 shard one column tile more can cost a whole round (8 %) on every wide launch.
 double shard_cost(const ShardModel& m, int64_t a, int64_t b) {
+    const int K = m.categories, slots = 512;
+    const double panel_us_per_col = 8.4e-3 * (K / 8.0) * (m.rows_inner / 721.0);
     double cost = 0;
     for (size_t j = 0; j < m.nodes.size(); ++j) {
         const std::vector<int64_t>& pv = m.prev[j];
         int64_t cols = 0;
         for (int64_t i = a; i < b; ++i) cols += pv[i] < a;
-        cost += (double)round_up64(cols, kBN);
+        const int ct = (int)(round_up64(cols, kBN) / kBN);
+        double best = 1e300;
+        int64_t best_tiles = 0;
+        for (int mi = 9; mi >= 4; --mi) {
+            const int64_t row_tiles = (m.rows_inner - 1 + 16 * mi - 1) / (16 * mi);
+            const int64_t tiles = row_tiles * ct * K;
+            const int64_t rounds = (tiles + slots - 1) / slots;
+            const double c = (double)rounds * mi * (1.0 + 0.006 * (9 - mi));
+            if (c < best * (1.0 - 1e-9)) { best = c; best_tiles = tiles; }
+        }
+        cost += best * (best_tiles <= slots / 2 ? 17.0 : 20.0) + 2.0 * panel_us_per_col * (double)(ct * kBN) + 6.0;
+    }
+    // the two branches under the root run over one column per (distinct) family of the shard; K4 reads that panel
+    {
+        const int ct = (int)(round_up64(b - a, kBN) / kBN);
+        double best = 1e300;
+        for (int mi = 9; mi >= 4; --mi) {
+            const int64_t tiles = (int64_t)((m.rows_root + 16 * mi - 1) / (16 * mi)) * ct * K;
+            best = std::min(best, (double)((tiles + slots - 1) / slots) * mi * (1.0 + 0.006 * (9 - mi)));
+        }
+        cost += 2.0 * best * 20.0 + 3.0 * panel_us_per_col * (double)(ct * kBN);
     }
     return cost;
 }
@@ -158,35 +184,48 @@ int plan_shards(const ShardModel& m, int n_shards, std::vector<int64_t>& bounds)
     for (int64_t i = 1; i < F; ++i) cum[i] += cum[i - 1];
     for (int r = 1; r < n_shards; ++r)
         bounds[r] = std::lower_bound(cum.begin(), cum.end(), cum[F - 1] * r / n_shards) - cum.begin();
-    auto fix = [&]() {                                   // never an empty shard
-        for (int r = 1; r < n_shards; ++r) bounds[r] = std::max(bounds[r], bounds[r - 1] + 1);
-        for (int r = n_shards - 1; r >= 1; --r) bounds[r] = std::min(bounds[r], bounds[r + 1] - 1);
+    auto fix = [&](std::vector<int64_t>& bd) {           // never an empty shard
+        bd[0] = 0; bd[n_shards] = F;
+        for (int r = 1; r < n_shards; ++r) bd[r] = std::max(bd[r], bd[r - 1] + 1);
+        for (int r = n_shards - 1; r >= 1; --r) bd[r] = std::min(bd[r], bd[r + 1] - 1);
     };
-    fix();
-    // refine: a pattern shared across a cut is paid on both sides, which the start ignores.  Move every cut towards
-    // the cheaper neighbour in proportion to the imbalance; a handful of sweeps brings the shards within a percent.
+    fix(bounds);
     std::vector<double> cost(n_shards);
+    auto eval = [&](const std::vector<int64_t>& bd) {
+        double hi = 0;
+        for (int r = 0; r < n_shards; ++r) { cost[r] = shard_cost(m, bd[r], bd[r + 1]); hi = std::max(hi, cost[r]); }
+        return hi;
+    };
+    // 1. a pattern shared across a cut is paid on both sides, which the start ignores: move every cut towards the
+    //    cheaper neighbour in proportion to the imbalance, a few damped sweeps
     std::vector<int64_t> best = bounds;
-    double best_spread = 1e300;
-    for (int sweep = 0; sweep < 12; ++sweep) {
-        double lo = 1e300, hi = 0;
-        for (int r = 0; r < n_shards; ++r) { cost[r] = shard_cost(m, bounds[r], bounds[r + 1]); lo = std::min(lo, cost[r]); hi = std::max(hi, cost[r]); }
-        if (hi / lo < best_spread) { best_spread = hi / lo; best = bounds; }
-        if (hi / lo < 1.005) break;
+    double best_hi = eval(bounds);
+    for (int sweep = 0; sweep < 10; ++sweep) {
         std::vector<int64_t> nb = bounds;
         for (int r = 1; r < n_shards; ++r) {
-            // cut r separates shards r-1 and r: shift it by the family count that evens their costs out at their
-            // present average cost per family, damped
             const double cl = cost[r - 1], cr = cost[r];
             const double per_l = cl / (double)(bounds[r] - bounds[r - 1]), per_r = cr / (double)(bounds[r + 1] - bounds[r]);
-            const double shift = 0.5 * (cr - cl) / (per_l + per_r);
-            nb[r] = bounds[r] + (int64_t)std::llround(0.7 * shift);
+            nb[r] = bounds[r] + (int64_t)std::llround(0.35 * (cr - cl) / (per_l + per_r));
         }
+        fix(nb);
         bounds = nb;
-        bounds[0] = 0; bounds[n_shards] = F;
-        fix();
+        const double hi = eval(bounds);
+        if (hi < best_hi) { best_hi = hi; best = bounds; }
     }
+    // 2. the cost is a step function of a shard's column counts (whole column tiles, whole rounds): a local search over
+    //    single cuts, steps from 1/16 of a shard down to 8 families, lowers the largest of the two neighbours
     bounds = best;
+    eval(bounds);
+    for (int64_t step = std::max<int64_t>(8, F / n_shards / 16); step >= 8; step /= 2) {
+        for (int pass = 0; pass < 2; ++pass)
+            for (int r = 1; r < n_shards; ++r)
+                for (int dir = -1; dir <= 1; dir += 2) {
+                    const int64_t nb = bounds[r] + dir * step;
+                    if (nb <= bounds[r - 1] || nb >= bounds[r + 1]) continue;
+                    const double cl = shard_cost(m, bounds[r - 1], nb), cr = shard_cost(m, nb, bounds[r + 1]);
+                    if (std::max(cl, cr) < std::max(cost[r - 1], cost[r]) * (1.0 - 1e-12)) { bounds[r] = nb; cost[r - 1] = cl; cost[r] = cr; }
+                }
+    }
     return CAFE_OK;
 }
 

@@ -283,60 +283,97 @@ hipError_t launch_leaf_gather(const GatherArgs& a, int n_categories, hipStream_t
     return hipGetLastError();
 }
 
-// One thread per family; rows of the root panel are read coalesced along the family axis.
+// kRedFam families x kRedSeg row segments per workgroup: thread (family, segment) walks the rows j = segment,
+// segment + kRedSeg, ... of its family's root column (a wave instruction reads kRedFam consecutive families of 64 / kRedFam
+// rows: full 128-byte lines), the segments are then combined in LDS.  Maxima do not depend on the order they are combined
+// in; the category sum is only tested against zero (all terms are non-negative).  NaN follows the reference's scan
+// (std::max_element / the `>` scan of gamma_core.cpp:158): a NaN at j = 0 is returned, a NaN elsewhere never wins a
+// comparison.  (One thread per family, 750 x 8 dependent strided loads, took 2.5 ms whatever the number of families.)
+constexpr int kRedFam = 16, kRedSeg = 16;
+__device__ inline double combine_max(double* sh, int fam, int seg, double v) {
+    sh[seg * kRedFam + fam] = v;
+    __syncthreads();
+    double best = sh[fam];
+    if (seg == 0)
+        for (int s2 = 1; s2 < kRedSeg; ++s2) { const double p = sh[s2 * kRedFam + fam]; if (p > best) best = p; }
+    __syncthreads();
+    return best;
+}
+__device__ inline double combine_sum(double* sh, int fam, int seg, double v) {
+    sh[seg * kRedFam + fam] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (seg == 0)
+        for (int s2 = 0; s2 < kRedSeg; ++s2) t += sh[s2 * kRedFam + fam];
+    __syncthreads();
+    return t;
+}
+
 __global__ __launch_bounds__(256) void root_reduce_kernel(const ReduceArgs a) {
-    const int64_t fl = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (fl >= a.nf) return;
+    __shared__ double sh[kRedFam * kRedSeg];
+    const int fam = threadIdx.x % kRedFam, seg = threadIdx.x / kRedFam;
+    const int64_t fl = (int64_t)blockIdx.x * kRedFam + fam;
+    const bool live = fl < a.nf;                            // (every thread reaches the barriers)
     const int64_t f = a.f0 + fl;
+    const double ninf = -__builtin_huge_val();
     if (a.model == 2) {
         // p-value path: the observed / simulated "max likelihood" is max_j L_root[j], no prior
         // (probability.cpp:313, :399)
         const double* col = a.root + fl;
-        double best = col[0];
-        for (int j = 1; j < a.R; ++j) {
-            const double L = col[(int64_t)j * a.ld];
-            if (L > best) best = L;
-        }
-        a.fam_out[f] = best;
-        a.failed[f] = 0;
+        double best = ninf;
+        if (live)
+            for (int j = seg; j < a.R; j += kRedSeg) {
+                const double L = col[(int64_t)j * a.ld];
+                if (j == 0 || L > best) best = L;
+            }
+        best = combine_max(sh, fam, seg, best);
+        if (live && seg == 0) { a.fam_out[f] = best; a.failed[f] = 0; }
         return;
     }
     if (a.model == 0) {
         // lnL_f = max_j( log L_j + log prior_j ), first maximum like std::max_element (base_model.cpp:94-101)
         const double* col = a.root + fl;
-        double best = 0.0;
-        for (int j = 0; j < a.R; ++j) {
-            const double full = log(col[(int64_t)j * a.ld]) + a.log_prior[j];
-            if (j == 0 || full > best) best = full;
-        }
-        a.fam_out[f] = best;
-        a.failed[f] = 0;
+        double best = ninf;
+        if (live)
+            for (int j = seg; j < a.R; j += kRedSeg) {
+                const double full = log(col[(int64_t)j * a.ld]) + a.log_prior[j];
+                if (j == 0 || full > best) best = full;
+            }
+        best = combine_max(sh, fam, seg, best);
+        if (live && seg == 0) { a.fam_out[f] = best; a.failed[f] = 0; }
         return;
     }
     double lik = 0.0;
     int fail = 0;
     for (int k = 0; k < a.K; ++k) {
         const double* col = a.root + (int64_t)k * a.panel_kstride + fl;
-        double sum = 0.0, best = 0.0;
-        for (int j = 0; j < a.R; ++j) {
-            const double L = col[(int64_t)j * a.ld];
-            sum += L;
-            const double full = L * a.prior[j];
-            if (j == 0 || full > best) best = full;
+        double sum = 0.0, best = ninf;
+        if (live)
+            for (int j = seg; j < a.R; j += kRedSeg) {
+                const double L = col[(int64_t)j * a.ld];
+                sum += L;
+                const double full = L * a.prior[j];
+                if (j == 0 || full > best) best = full;
+            }
+        sum = combine_sum(sh, fam, seg, sum);
+        best = combine_max(sh, fam, seg, best);
+        if (live && seg == 0) {
+            if (sum == 0.0) fail = 1;                      // "saturation", gamma_core.cpp:152
+            const double cl = best * a.cat_probs[k];        // gamma_core.cpp:162
+            a.cat_out[f * a.K + k] = cl;
+            lik += cl;                                      // gamma_core.cpp:207
         }
-        if (sum == 0.0) fail = 1;                          // "saturation", gamma_core.cpp:152
-        const double cl = best * a.cat_probs[k];            // gamma_core.cpp:162
-        a.cat_out[f * a.K + k] = cl;
-        lik += cl;                                          // gamma_core.cpp:207
     }
-    a.fam_lik[f] = lik;
-    a.fam_out[f] = log(lik);
-    a.failed[f] = fail;
+    if (live && seg == 0) {
+        a.fam_lik[f] = lik;
+        a.fam_out[f] = log(lik);
+        a.failed[f] = fail;
+    }
 }
 
 hipError_t launch_root_reduce(const ReduceArgs& a, hipStream_t stream) {
     if (a.nf <= 0) return hipSuccess;
-    dim3 grid((unsigned)((a.nf + 255) / 256)), block(256);
+    dim3 grid((unsigned)((a.nf + kRedFam - 1) / kRedFam)), block(256);
     (void)hipGetLastError();
     hipLaunchKernelGGL(root_reduce_kernel, grid, block, 0, stream, a);
     return hipGetLastError();

@@ -52,7 +52,7 @@ def test_shard_plan_is_a_balanced_partition(world):
     assert all(np.array_equal(a, b) for a, b in zip(plan, again))                        # every rank derives the same plan
     if world > 1:
         cost = np.array([_distinct_columns(pb, p, tile=128) for p in plan], dtype=float)   # K2's tiles are 128 columns wide
-        assert cost.max() / cost.min() < 1.12, cost                                       # by distinct patterns, not family count
+        assert cost.max() / cost.min() < 1.25, cost                                       # by (predicted time over) distinct patterns, not family count
         assert max(len(p) for p in plan) > min(len(p) for p in plan)                      # ... which is not an even family count
         # look-alikes share a shard: the shards together hold fewer distinct columns than contiguous blocks of the table
         blocks = np.array_split(np.arange(pb.n_families), world)
