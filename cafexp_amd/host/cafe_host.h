@@ -26,6 +26,10 @@
 #include <vector>
 
 struct cafe_ctx;
+struct cafe_sharded;
+struct cafe_params;
+struct cafe_family_out;
+struct cafe_sharded;
 
 namespace cafe {
 
@@ -249,8 +253,17 @@ protected:
     int _ctx_categories = 0;
     int _ctx_lambda_sig = -1;                                        // lambda kind/count the context was built for
     int _device = 0;
+    // several GPUs: the scorer calls go to a cafe_sharded (family shards, one host thread per device, one RCCL
+    // all-reduce per call); what runs once after the search (reconstruction, p-values) stays on the first device
+    std::vector<int> _devices;
+    cafe_sharded* _sharded = nullptr;
+    int _sharded_categories = 0, _sharded_lambda_sig = -1;
     std::vector<const clade*> _order;                                // post-order used to flatten
-    void ensure_context(int max_categories);
+    void ensure_context(int max_categories);                         // single-device context (_ctx)
+    void ensure_scorer(int max_categories);                          // what infer_family_likelihoods calls: _sharded or _ctx
+    int score_call(const cafe_params* pr, double* score);
+    int family_results_call(const cafe_family_out* out);
+    const char* scorer_error() const;
     // prior as floats (compute(j), j < R), error-model table, lambdas in index order
     void gather_call_inputs(root_equilibrium_distribution* prior, const std::map<int, int>& rootdist, std::vector<float>& prior_f,
                             std::vector<double>& err_table, std::vector<double>& lambdas) const;
@@ -262,6 +275,7 @@ public:
     using model::model;
     ~hip_model_base() override;
     void set_device(int d) { _device = d; }
+    void set_devices(const std::vector<int>& d) { _devices = d; if (!d.empty()) _device = d[0]; }
     // compute_pvalues with the Monte-Carlo simulation on the device too (cafe_pvalues): statistical agreement with the
     // reference's procedure, not draw for draw
     std::vector<double> device_pvalues(int number_of_simulations, uint64_t seed);

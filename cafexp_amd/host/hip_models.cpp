@@ -15,10 +15,24 @@ namespace cafe {
 
 hip_model_base::~hip_model_base() {
     if (_ctx) cafe_destroy(_ctx);
+    if (_sharded) cafe_sharded_destroy(_sharded);
 }
+
+// devices: nullptr / 0 -> one context on `device` (returned through *ctx); else a sharded scorer over the listed devices
+static void create_device_objects(const lambda* lam, const std::vector<const clade*>& order, const int32_t* counts, int64_t n_families,
+                                  int max_family_size, int max_root_family_size, int max_categories, int n_deviations, int device,
+                                  const std::vector<int>* devices, cafe_ctx** ctx, cafe_sharded** sharded);
 
 cafe_ctx* create_device_context(const lambda* lam, const std::vector<const clade*>& order, const int32_t* counts, int64_t n_families,
                                  int max_family_size, int max_root_family_size, int max_categories, int n_deviations, int device) {
+    cafe_ctx* ctx = nullptr;
+    create_device_objects(lam, order, counts, n_families, max_family_size, max_root_family_size, max_categories, n_deviations, device, nullptr, &ctx, nullptr);
+    return ctx;
+}
+
+static void create_device_objects(const lambda* lam, const std::vector<const clade*>& order, const int32_t* counts, int64_t n_families,
+                                  int max_family_size, int max_root_family_size, int max_categories, int n_deviations, int device,
+                                  const std::vector<int>* devices, cafe_ctx** out_ctx, cafe_sharded** out_sharded) {
     const int n = (int)order.size();
     std::map<const clade*, int> index;
     for (int i = 0; i < n; ++i) index[order[i]] = i;
@@ -41,9 +55,26 @@ cafe_ctx* create_device_context(const lambda* lam, const std::vector<const clade
     pb.n_deviations = n_deviations;
     pb.device = device; pb.flags = 0; pb.workspace_limit = 0;
     char err[512];
-    cafe_ctx* ctx = cafe_create(&pb, err, sizeof err);
-    if (!ctx) throw std::runtime_error(std::string("cafe_create: ") + err);
-    return ctx;
+    if (devices && devices->size() > 1) {
+        std::vector<int32_t> dev(devices->begin(), devices->end());
+        *out_sharded = cafe_create_sharded(&pb, dev.data(), (int32_t)dev.size(), err, sizeof err);
+        if (!*out_sharded) throw std::runtime_error(std::string("cafe_create_sharded: ") + err);
+        return;
+    }
+    *out_ctx = cafe_create(&pb, err, sizeof err);
+    if (!*out_ctx) throw std::runtime_error(std::string("cafe_create: ") + err);
+}
+
+static std::vector<int32_t> flatten_counts(const clade* tree, const std::vector<gene_family>& fams, std::vector<const clade*>& order) {
+    order = tree->post_order();
+    std::vector<const clade*> leaves;
+    for (const clade* c : order) if (c->is_leaf()) leaves.push_back(c);
+    const int T = (int)leaves.size();
+    const int64_t F = (int64_t)fams.size();
+    std::vector<int32_t> counts((size_t)F * T);
+    for (int64_t f = 0; f < F; ++f)
+        for (int t = 0; t < T; ++t) counts[(size_t)f * T + t] = fams[f].get_species_size(leaves[t]->get_taxon_name());
+    return counts;
 }
 
 void hip_model_base::ensure_context(int max_categories) {
@@ -53,17 +84,34 @@ void hip_model_base::ensure_context(int max_categories) {
     if (_ctx) { cafe_destroy(_ctx); _ctx = nullptr; }
     if (!_p_tree || !_p_gene_families || _p_gene_families->empty())
         throw std::runtime_error("hip model: a tree and a non-empty family list are required");
-    _order = _p_tree->post_order();
-    std::vector<const clade*> leaves;
-    for (const clade* c : _order) if (c->is_leaf()) leaves.push_back(c);
-    const int T = (int)leaves.size();
-    const int64_t F = (int64_t)_p_gene_families->size();
-    std::vector<int32_t> counts((size_t)F * T);
-    for (int64_t f = 0; f < F; ++f)
-        for (int t = 0; t < T; ++t) counts[(size_t)f * T + t] = (*_p_gene_families)[f].get_species_size(leaves[t]->get_taxon_name());
-    _ctx = create_device_context(_p_lambda, _order, counts.data(), F, _max_family_size, _max_root_family_size, max_categories,
-                                 _p_error_model ? (int)_p_error_model->n_deviations() : 0, _device);
+    const std::vector<int32_t> counts = flatten_counts(_p_tree, *_p_gene_families, _order);
+    _ctx = create_device_context(_p_lambda, _order, counts.data(), (int64_t)_p_gene_families->size(), _max_family_size, _max_root_family_size,
+                                 max_categories, _p_error_model ? (int)_p_error_model->n_deviations() : 0, _device);
     _ctx_categories = max_categories;
+}
+
+void hip_model_base::ensure_scorer(int max_categories) {
+    if (_devices.size() <= 1) { ensure_context(max_categories); return; }
+    const int sig = _p_lambda->count() * 2 + (dynamic_cast<const multiple_lambda*>(_p_lambda) ? 1 : 0);
+    if (_sharded && max_categories <= _sharded_categories && sig == _sharded_lambda_sig) return;
+    _sharded_lambda_sig = sig;
+    if (_sharded) { cafe_sharded_destroy(_sharded); _sharded = nullptr; }
+    if (!_p_tree || !_p_gene_families || _p_gene_families->empty())
+        throw std::runtime_error("hip model: a tree and a non-empty family list are required");
+    const std::vector<int32_t> counts = flatten_counts(_p_tree, *_p_gene_families, _order);
+    create_device_objects(_p_lambda, _order, counts.data(), (int64_t)_p_gene_families->size(), _max_family_size, _max_root_family_size, max_categories,
+                          _p_error_model ? (int)_p_error_model->n_deviations() : 0, _device, &_devices, nullptr, &_sharded);
+    _sharded_categories = max_categories;
+}
+
+int hip_model_base::score_call(const cafe_params* pr, double* score) {
+    return _sharded ? cafe_sharded_score(_sharded, pr, score, nullptr) : cafe_score(_ctx, pr, score, nullptr);
+}
+int hip_model_base::family_results_call(const cafe_family_out* out) {
+    return _sharded ? cafe_sharded_family_results(_sharded, out) : cafe_family_results(_ctx, out);
+}
+const char* hip_model_base::scorer_error() const {
+    return _sharded ? cafe_sharded_last_error(_sharded) : cafe_last_error(_ctx);
 }
 
 void hip_model_base::gather_call_inputs(root_equilibrium_distribution* prior, const std::map<int, int>& rootdist, std::vector<float>& prior_f,
@@ -94,7 +142,7 @@ double hip_base_model::infer_family_likelihoods(root_equilibrium_distribution* p
         _monitor.rejects++;
         return std::numeric_limits<double>::infinity();
     }
-    ensure_context(1);
+    ensure_scorer(1);
     std::vector<float> prior_f;
     std::vector<double> err, lambdas;
     gather_call_inputs(prior, rootdist, prior_f, err, lambdas);
@@ -106,9 +154,9 @@ double hip_base_model::infer_family_likelihoods(root_equilibrium_distribution* p
     cafe_family_out out{};
     out.family_lnl = lnl.data();
     double score = 0;
-    if (cafe_score(_ctx, &pr, &score, nullptr) != CAFE_OK) throw std::runtime_error(std::string("cafe_score: ") + cafe_last_error(_ctx));
+    if (score_call(&pr, &score) != CAFE_OK) throw std::runtime_error(std::string("cafe_score: ") + scorer_error());
     results.resize(F);
-    if (cafe_family_results(_ctx, &out) == CAFE_OK)
+    if (family_results_call(&out) == CAFE_OK)
         for (size_t i = 0; i < F; ++i) {                         // results[i] = {id, 0, 0, 0, lnL_i, false} (base_model.cpp:105)
             results[i] = family_info_stash();
             results[i].family_id = (*_p_gene_families)[i].id();
@@ -164,7 +212,7 @@ double hip_gamma_model::infer_family_likelihoods(root_equilibrium_distribution* 
         return std::numeric_limits<double>::infinity();
     }
     const int K = (int)_gamma_cat_probs.size();
-    ensure_context(K);
+    ensure_scorer(K);
     std::vector<float> prior_f;
     std::vector<double> err, lambdas;
     gather_call_inputs(prior, rootdist, prior_f, err, lambdas);
@@ -172,13 +220,13 @@ double hip_gamma_model::infer_family_likelihoods(root_equilibrium_distribution* 
     pr.model = CAFE_MODEL_GAMMA; pr.lambdas = lambdas.data(); pr.n_categories = K; pr.multipliers = _lambda_multipliers.data();
     pr.cat_probs = _gamma_cat_probs.data(); pr.alpha = _alpha; pr.prior = prior_f.data(); pr.error_model = err.empty() ? nullptr : err.data();
     double score = 0;
-    if (cafe_score(_ctx, &pr, &score, nullptr) != CAFE_OK) throw std::runtime_error(std::string("cafe_score: ") + cafe_last_error(_ctx));
+    if (score_call(&pr, &score) != CAFE_OK) throw std::runtime_error(std::string("cafe_score: ") + scorer_error());
     const size_t F = _p_gene_families->size();
     std::vector<double> cat((size_t)F * K), fam(F);
     std::vector<int32_t> failed(F);
     cafe_family_out out{};
     out.category_likelihood = cat.data(); out.family_likelihood = fam.data(); out.failed = failed.data();
-    if (cafe_family_results(_ctx, &out) != CAFE_OK) return score;           // rejected on the device side without results
+    if (family_results_call(&out) != CAFE_OK) return score;                 // rejected on the device side without results
     if (std::isinf(score)) {                                                // a category summed to zero: gamma_core.cpp:227-236
         for (size_t i = 0; i < F; ++i)
             if (failed[i]) _monitor.failure_count[(*_p_gene_families)[i].id()]++;

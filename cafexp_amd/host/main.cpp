@@ -17,9 +17,10 @@ using namespace cafe;
 static void usage() {
     std::fprintf(stderr,
         "usage: cafexp_hip -t TREE -i FAMILIES [-l LAMBDA | -m L1,L2,.. -y LAMBDA_TREE | -y LAMBDA_TREE] [-k K] [-a ALPHA]\n"
-        "                  [-e [ERRMODEL]] [-p [POISSON_LAMBDA]] [-f ROOTDIST] [-z] [-s SEED] [-I MAXITER] [-d DEVICE] [--reps N] [--family-out FILE] [-o OUTDIR] [--limit N]\n"
+        "                  [-e [ERRMODEL]] [-p [POISSON_LAMBDA]] [-f ROOTDIST] [-z] [-s SEED] [-I MAXITER] [-d DEVICE | --gpus N] [--reps N] [--family-out FILE] [-o OUTDIR] [--limit N]\n"
         "                  [--pvalues NSIM [--pvalues-device] [--pvalues-out FILE] [--pvalues-cond FILE:K]] [--sizes M,R]\n"
-        "                  [--reconstruct [-P PVALUE]]   (with -o: the reports of reconstruction::write_results)\n");
+        "                  [--reconstruct [-P PVALUE]]   (with -o: the reports of reconstruction::write_results)\n"
+        "  --gpus N: the scorer calls shard the families over devices 0..N-1 (one host thread per GPU, one RCCL all-reduce per call)\n");
 }
 
 static std::string slurp_first_line(const std::string& path) {
@@ -44,7 +45,7 @@ int main(int argc, char** argv) {
     double test_pvalue = 0.05;                                   // input_parameters::pvalue default (io.h)
     long limit = -1;
     double fixed_lambda = 0, fixed_alpha = -1, poisson = 0;
-    int k = 1, device = 0, max_iter = 300, reps = 1;
+    int k = 1, device = 0, max_iter = 300, reps = 1, n_gpus = 1;
     bool use_err = false, use_poisson = false, keep_all = false;
     unsigned seed = 0;
     bool have_seed = false;
@@ -66,6 +67,7 @@ int main(int argc, char** argv) {
         else if (a == "-s") { seed = (unsigned)std::stoul(next()); have_seed = true; }
         else if (a == "-I") max_iter = std::stoi(next());
         else if (a == "-d") device = std::stoi(next());
+        else if (a == "--gpus") n_gpus = std::stoi(next());
         else if (a == "--reps") reps = std::stoi(next());
         else if (a == "--family-out") family_out = next();
         else if (a == "-o") out_dir = next();
@@ -145,6 +147,11 @@ int main(int argc, char** argv) {
             mdl.reset(new hip_base_model(start_lambda, d.p_tree.get(), &d.gene_families, d.max_family_size, d.max_root_family_size, em));
         }
         mdl->set_device(device);
+        if (n_gpus > 1) {
+            std::vector<int> devs(n_gpus);
+            for (int g = 0; g < n_gpus; ++g) devs[g] = g;
+            mdl->set_devices(devs);
+        }
 
         std::unique_ptr<inference_optimizer_scorer> scorer(mdl->get_lambda_optimizer(d));
         std::unique_ptr<lambda> owned_lambda;

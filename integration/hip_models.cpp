@@ -50,17 +50,21 @@ std::vector<float> root_prior_for_reconstruction(root_equilibrium_distribution* 
 
 hip_device_context::~hip_device_context() {
     if (_ctx) cafe_destroy(_ctx);
+    if (_sharded) cafe_sharded_destroy(_sharded);
 }
 
-cafe_ctx* hip_device_context::ensure(const lambda* p_lambda, const clade* p_tree, const std::vector<gene_family>* p_families,
-                                     int max_family_size, int max_root_family_size, int categories, const error_model* p_error_model) {
+bool hip_device_context::matches(const signature& s, const lambda* p_lambda, const clade* p_tree, const std::vector<gene_family>* p_families,
+                                 int categories, const error_model* p_error_model) const {
+    return s.families == p_families && s.n_families == p_families->size() && s.tree == p_tree && s.lambda_count == p_lambda->count() &&
+           s.multiple == (dynamic_cast<const multiple_lambda*>(p_lambda) != nullptr) && categories <= s.categories &&
+           s.n_deviations == (p_error_model ? (int)p_error_model->n_deviations() : 0);
+}
+
+void hip_device_context::create(bool sharded, const lambda* p_lambda, const clade* p_tree, const std::vector<gene_family>* p_families,
+                                int max_family_size, int max_root_family_size, int categories, const error_model* p_error_model) {
     if (!p_tree || !p_families || p_families->empty()) throw std::runtime_error("hip model: a tree and a non-empty family list are required");
     const bool multiple = dynamic_cast<const multiple_lambda*>(p_lambda) != nullptr;
     const int n_dev = p_error_model ? (int)p_error_model->n_deviations() : 0;
-    if (_ctx && _families == p_families && _n_families == p_families->size() && _tree == p_tree && _lambda_count == p_lambda->count() &&
-        _multiple == multiple && categories <= _categories && _n_deviations == n_dev)
-        return _ctx;
-    if (_ctx) { cafe_destroy(_ctx); _ctx = nullptr; }
     _order.clear();
     p_tree->apply_reverse_level_order([this](const clade* c) { _order.push_back(c); });     // children before parents (clade.cpp:255)
     const int n = (int)_order.size();
@@ -87,11 +91,48 @@ cafe_ctx* hip_device_context::ensure(const lambda* p_lambda, const clade* p_tree
     pb.n_lambdas = p_lambda->count(); pb.single_lambda = multiple ? 0 : 1; pb.max_categories = categories;
     pb.n_deviations = n_dev; pb.device = device;
     char err[512];
-    _ctx = cafe_create(&pb, err, sizeof err);
-    if (!_ctx) throw std::runtime_error(std::string("cafe_create: ") + err);
-    _families = p_families; _n_families = F; _tree = p_tree; _lambda_count = p_lambda->count(); _multiple = multiple;
-    _categories = categories; _n_deviations = n_dev;
+    signature sig;
+    sig.families = p_families; sig.n_families = F; sig.tree = p_tree; sig.lambda_count = p_lambda->count(); sig.multiple = multiple;
+    sig.categories = categories; sig.n_deviations = n_dev;
+    if (sharded) {
+        if (_sharded) { cafe_sharded_destroy(_sharded); _sharded = nullptr; }
+        std::vector<int32_t> devices(n_gpus);
+        std::iota(devices.begin(), devices.end(), 0);
+        _sharded = cafe_create_sharded(&pb, devices.data(), n_gpus, err, sizeof err);
+        if (!_sharded) throw std::runtime_error(std::string("cafe_create_sharded: ") + err);
+        _sharded_sig = sig;
+    } else {
+        if (_ctx) { cafe_destroy(_ctx); _ctx = nullptr; }
+        _ctx = cafe_create(&pb, err, sizeof err);
+        if (!_ctx) throw std::runtime_error(std::string("cafe_create: ") + err);
+        _ctx_sig = sig;
+    }
+}
+
+cafe_ctx* hip_device_context::ensure(const lambda* p_lambda, const clade* p_tree, const std::vector<gene_family>* p_families,
+                                     int max_family_size, int max_root_family_size, int categories, const error_model* p_error_model) {
+    if (!_ctx || !matches(_ctx_sig, p_lambda, p_tree, p_families, categories, p_error_model))
+        create(false, p_lambda, p_tree, p_families, max_family_size, max_root_family_size, categories, p_error_model);
     return _ctx;
+}
+
+void hip_device_context::ensure_scorer(const lambda* p_lambda, const clade* p_tree, const std::vector<gene_family>* p_families,
+                                       int max_family_size, int max_root_family_size, int categories, const error_model* p_error_model) {
+    if (n_gpus <= 1) { ensure(p_lambda, p_tree, p_families, max_family_size, max_root_family_size, categories, p_error_model); return; }
+    if (!_sharded || !matches(_sharded_sig, p_lambda, p_tree, p_families, categories, p_error_model))
+        create(true, p_lambda, p_tree, p_families, max_family_size, max_root_family_size, categories, p_error_model);
+}
+
+void hip_device_context::score(const cafe_params* params, double* neg_lnl) {
+    if (n_gpus > 1) {
+        if (cafe_sharded_score(_sharded, params, neg_lnl, nullptr) != CAFE_OK) throw std::runtime_error(std::string("cafe_sharded_score: ") + cafe_sharded_last_error(_sharded));
+    } else if (cafe_score(_ctx, params, neg_lnl, nullptr) != CAFE_OK) {
+        fail("cafe_score", _ctx);
+    }
+}
+
+bool hip_device_context::family_results(const cafe_family_out* out) {
+    return (n_gpus > 1 ? cafe_sharded_family_results(_sharded, out) : cafe_family_results(_ctx, out)) == CAFE_OK;
 }
 
 void hip_call_inputs::gather(root_equilibrium_distribution* p_prior, const std::map<int, int>& rootdist, const lambda* p_lambda,
@@ -123,19 +164,19 @@ double hip_base_model::infer_family_likelihoods(root_equilibrium_distribution* p
         _monitor.Event_InferenceAttempt_InvalidValues();
         return -log(0);
     }
-    cafe_ctx* ctx = _dev.ensure(_p_lambda, _p_tree, _p_gene_families, _max_family_size, _max_root_family_size, 1, _p_error_model);
+    _dev.ensure_scorer(_p_lambda, _p_tree, _p_gene_families, _max_family_size, _max_root_family_size, 1, _p_error_model);
     hip_call_inputs in;
     in.gather(prior, root_distribution_map, _p_lambda, _p_error_model, _max_family_size, _max_root_family_size);
     cafe_params pr = {};
     pr.model = CAFE_MODEL_BASE; pr.lambdas = in.lambdas.data(); pr.n_categories = 1; pr.prior = in.prior.data();
     pr.error_model = in.error_table.empty() ? nullptr : in.error_table.data();
     double score = 0;
-    if (cafe_score(ctx, &pr, &score, nullptr) != CAFE_OK) fail("cafe_score", ctx);
+    _dev.score(&pr, &score);
     const size_t F = _p_gene_families->size();
     std::vector<double> lnl(F);
     cafe_family_out out = {};
     out.family_lnl = lnl.data();
-    if (cafe_family_results(ctx, &out) != CAFE_OK) fail("cafe_family_results", ctx);
+    if (!_dev.family_results(&out)) throw std::runtime_error("cafe_family_results failed after a valid base-model call");
     results.resize(F);
     for (size_t i = 0; i < F; ++i)                                  // base_model.cpp:105
         results[i] = family_info_stash(_p_gene_families->at(i).id(), 0.0, 0.0, 0.0, lnl[i], false);
@@ -189,7 +230,7 @@ double hip_gamma_model::infer_family_likelihoods(root_equilibrium_distribution* 
     std::vector<double> cat_probs, multipliers;
     current_categories(cat_probs, multipliers);
     const int K = (int)cat_probs.size();
-    cafe_ctx* ctx = _dev.ensure(_p_lambda, _p_tree, _p_gene_families, _max_family_size, _max_root_family_size, K, _p_error_model);
+    _dev.ensure_scorer(_p_lambda, _p_tree, _p_gene_families, _max_family_size, _max_root_family_size, K, _p_error_model);
     hip_call_inputs in;
     in.gather(prior, root_distribution_map, _p_lambda, _p_error_model, _max_family_size, _max_root_family_size);
     cafe_params pr = {};
@@ -197,13 +238,13 @@ double hip_gamma_model::infer_family_likelihoods(root_equilibrium_distribution* 
     pr.cat_probs = cat_probs.data(); pr.alpha = _explicit_categories ? 0.0 : get_alpha(); pr.prior = in.prior.data();
     pr.error_model = in.error_table.empty() ? nullptr : in.error_table.data();
     double score = 0;
-    if (cafe_score(ctx, &pr, &score, nullptr) != CAFE_OK) fail("cafe_score", ctx);
+    _dev.score(&pr, &score);
     const size_t F = _p_gene_families->size();
     std::vector<double> cat(F * K), fam(F);
     std::vector<int32_t> failed(F);
     cafe_family_out out = {};
     out.category_likelihood = cat.data(); out.family_likelihood = fam.data(); out.failed = failed.data();
-    if (cafe_family_results(ctx, &out) != CAFE_OK) return score;     // rejected before any family was pruned
+    if (!_dev.family_results(&out)) return score;                    // rejected before any family was pruned
     if (std::isinf(score)) {                                        // a category's root vector summed to 0: gamma_core.cpp:227-236
         for (size_t i = 0; i < F; ++i)
             if (failed[i]) _monitor.Event_InferenceAttempt_Saturation(_p_gene_families->at(i).id());

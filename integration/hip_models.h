@@ -38,18 +38,30 @@ class matrix_cache;
 //! max sizes and the lambda's shape are fixed by then) and rebuilt when one of them is replaced (model::set_families,
 //! model::initialize_lambda).
 class hip_device_context {
-    cafe_ctx* _ctx = nullptr;
-    const void* _families = nullptr;
-    size_t _n_families = 0;
-    const void* _tree = nullptr;
-    int _lambda_count = 0, _categories = 0, _n_deviations = 0;
-    bool _multiple = false;
+    struct signature {
+        const void* families = nullptr; size_t n_families = 0; const void* tree = nullptr;
+        int lambda_count = 0, categories = 0, n_deviations = 0; bool multiple = false;
+    };
+    cafe_ctx* _ctx = nullptr;                // one device: scorer calls and everything after the search
+    cafe_sharded* _sharded = nullptr;        // n_gpus > 1: the scorer calls (family shards + one RCCL all-reduce per call)
+    signature _ctx_sig, _sharded_sig;
     cladevector _order;                      // children before parents; index = node id of the C ABI
+    bool matches(const signature& s, const lambda* p_lambda, const clade* p_tree, const std::vector<gene_family>* p_families,
+                 int categories, const error_model* p_error_model) const;
+    void create(bool sharded, const lambda* p_lambda, const clade* p_tree, const std::vector<gene_family>* p_families,
+                int max_family_size, int max_root_family_size, int categories, const error_model* p_error_model);
 public:
-    int device = 0;
+    int device = 0;                          // the single device / the first of the shard devices
+    int n_gpus = 1;                          // > 1: devices 0 .. n_gpus-1 share the families of every scorer call
     ~hip_device_context();
+    //! the single-device context (created on first use)
     cafe_ctx* ensure(const lambda* p_lambda, const clade* p_tree, const std::vector<gene_family>* p_families,
                      int max_family_size, int max_root_family_size, int categories, const error_model* p_error_model);
+    //! what a scorer call runs on: the sharded scorer when n_gpus > 1, else the single-device context
+    void ensure_scorer(const lambda* p_lambda, const clade* p_tree, const std::vector<gene_family>* p_families,
+                       int max_family_size, int max_root_family_size, int categories, const error_model* p_error_model);
+    void score(const cafe_params* params, double* neg_lnl);              // throws std::runtime_error on a structural error
+    bool family_results(const cafe_family_out* out);                     // false: the call was rejected (+inf), no results
     cafe_ctx* get() const { return _ctx; }
     const cladevector& order() const { return _order; }
 };
@@ -66,8 +78,8 @@ class hip_base_model : public base_model {
     hip_device_context _dev;
 public:
     hip_base_model(lambda* p_lambda, const clade* p_tree, const std::vector<gene_family>* p_gene_families,
-                   int max_family_size, int max_root_family_size, error_model* p_error_model, int device = 0)
-        : base_model(p_lambda, p_tree, p_gene_families, max_family_size, max_root_family_size, p_error_model) { _dev.device = device; }
+                   int max_family_size, int max_root_family_size, error_model* p_error_model, int device = 0, int n_gpus = 1)
+        : base_model(p_lambda, p_tree, p_gene_families, max_family_size, max_root_family_size, p_error_model) { _dev.device = device; _dev.n_gpus = n_gpus; }
 
     double infer_family_likelihoods(root_equilibrium_distribution* prior, const std::map<int, int>& root_distribution_map,
                                     const lambda* p_lambda) override;
@@ -85,13 +97,13 @@ class hip_gamma_model : public gamma_model {
     void current_categories(std::vector<double>& cat_probs, std::vector<double>& multipliers) const;
 public:
     hip_gamma_model(lambda* p_lambda, clade* p_tree, std::vector<gene_family>* p_gene_families, int max_family_size,
-                    int max_root_family_size, int n_gamma_cats, double fixed_alpha, error_model* p_error_model, int device = 0)
-        : gamma_model(p_lambda, p_tree, p_gene_families, max_family_size, max_root_family_size, n_gamma_cats, fixed_alpha, p_error_model) { _dev.device = device; }
+                    int max_root_family_size, int n_gamma_cats, double fixed_alpha, error_model* p_error_model, int device = 0, int n_gpus = 1)
+        : gamma_model(p_lambda, p_tree, p_gene_families, max_family_size, max_root_family_size, n_gamma_cats, fixed_alpha, p_error_model) { _dev.device = device; _dev.n_gpus = n_gpus; }
     hip_gamma_model(lambda* p_lambda, clade* p_tree, std::vector<gene_family>* p_gene_families, int max_family_size,
                     int max_root_family_size, std::vector<double> gamma_categories, std::vector<double> multipliers,
-                    error_model* p_error_model, int device = 0)
+                    error_model* p_error_model, int device = 0, int n_gpus = 1)
         : gamma_model(p_lambda, p_tree, p_gene_families, max_family_size, max_root_family_size, gamma_categories, multipliers, p_error_model),
-          _explicit_categories(true), _explicit_cat_probs(gamma_categories) { _dev.device = device; }
+          _explicit_categories(true), _explicit_cat_probs(gamma_categories) { _dev.device = device; _dev.n_gpus = n_gpus; }
 
     double infer_family_likelihoods(root_equilibrium_distribution* prior, const std::map<int, int>& root_distribution_map,
                                     const lambda* p_lambda) override;

@@ -517,3 +517,71 @@ def test_sharded_scorer_on_one_device_and_comm_attach(capi, oracle):
     assert one.score(pr, alpha=1.5) == v1
     one.comm_detach()
     assert one.score(pr, alpha=1.5) == v1
+
+
+def test_gamma_zero_sum_rule_at_the_edge_of_fp64(capi, oracle):
+    """The same fixture as tests/test_oracle_pinned.py::test_gamma_zero_sum_rule_at_the_edge_of_fp64, through the C ABI: the
+    device must call a category "zero" exactly where the reference does (denormal root vectors are NOT zero), i.e. the
+    MFMA path must neither flush denormals nor lose the last few denormal units to another summation order."""
+    import json
+    import os
+    from helpers import read
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_borderline.json")))
+    tree = P.parse_newick(read(g["args"]["tree"]))
+    species, ids, counts = P.read_family_table(read(g["args"]["families"]))
+    pb = P.build_problem(tree, species, ids, counts)
+    probs, mult = oracle.discrete_gamma(g["args"]["k"], g["args"]["alpha"])
+    ctx = capi.Context(pb, max_categories=4)
+    for lam, e in g["cases"].items():
+        pr = P.Params(lambdas=np.array([float(lam)]), prior=P.prior_uniform(pb.max_root_family_size), multipliers=mult, cat_probs=probs)
+        want = float(e["neg_lnl"])
+        got = ctx.score(pr, alpha=g["args"]["alpha"])
+        if math.isinf(want):
+            assert got == want, lam
+            continue
+        assert rel_err(got, want) <= SCORE_TOL, lam
+        res = ctx.family_results(4)
+        wc = np.array(e["category_likelihood"], dtype=float).reshape(res["category_likelihood"].shape)
+        big = wc > 1e-290
+        assert np.allclose(res["category_likelihood"][big], wc[big], rtol=1e-9)
+        assert not res["failed"].any()
+
+
+def test_leaf_nodes_are_one_hot_known_answer(capi):
+    """test.cpp:1665 (likelihood_computer_sets_leaf_nodes_correctly): leaf A = 3 -> e_3, leaf B = 6 -> e_6.  The device never
+    materialises a leaf vector: P . e_x is column x of the branch's matrix, so the replay is that the root vector of
+    (A:1,B:3) equals P_A[1.., 3] * P_B[1.., 6] of the matrices the same call built."""
+    pb = _ab_problem("(A:1,B:3);", [{"A": 3, "B": 6}], 20, 20)
+    ctx = capi.Context(pb)
+    ctx.score(P.Params(lambdas=np.array([0.045]), prior=P.prior_uniform(20)))
+    nodes = {name: i for i, name in enumerate(pb.node_names)}
+    PA, PB = ctx.matrix(nodes["A"]), ctx.matrix(nodes["B"])
+    want = PA[1:21, 3] * PB[1:21, 6]
+    got = ctx.root_likelihoods(0)
+    assert np.array_equal(got, want)
+
+
+def test_only_the_needed_matrices_are_built_documented_difference(capi, oracle):
+    """test.cpp:856 (precalculate_matrices_calculates_all_lambdas_all_branchlengths) pins that the reference builds the full
+    {lambda} x {branch length} cross product (4 x 3 = 12 matrices).  Here a branch only ever reads the matrix of ITS lambda, so
+    one matrix per distinct (quantized branch length, lambda index) pair is built -- a documented difference in work, not
+    in values: every matrix that is read equals the oracle's."""
+    tree = P.parse_newick("((A:1,B:2):3,(C:1,D:2):3);")
+    lam_tree = P.parse_newick("((A:1,B:1):1,(C:2,D:1):1);", lambda_tree=True)      # only the branch above C has the second lambda
+    names = [l.name for l in tree.leaves()]
+    pb = P.build_problem(tree, names, ["f0", "f1"], np.array([[1, 2, 3, 2], [2, 2, 1, 1]]), lambda_tree=lam_tree, root_filter=False,
+                         max_family_size=20, max_root_family_size=15)
+    ctx = capi.Context(pb)
+    lambdas = np.array([0.01, 0.03])
+    ctx.score(P.Params(lambdas=lambdas, prior=P.prior_uniform(15)))
+    st = ctx.stats()
+    pairs = {(round(float(pb.branch_length[v]) * 1000), int(pb.lambda_index[v])) for v in range(pb.n_nodes) if pb.parent[v] >= 0}
+    assert st["n_matrices"] == len(pairs) == 4 < 2 * 3              # the reference's cache would hold 2 lambdas x 3 lengths = 6
+    n = max(20, 15) + 1
+    for v in range(pb.n_nodes):
+        if pb.parent[v] < 0:
+            continue
+        want = oracle.build_matrix(n, float(lambdas[pb.lambda_index[v]]), float(pb.branch_length[v]))
+        got = ctx.matrix(v)
+        cols = n if pb.leaf_taxon[v] >= 0 else 21
+        assert np.abs(got[:, :cols] - want[:, :cols]).max() <= VEC_TOL

@@ -6,6 +6,8 @@ CPU only; no product code is exercised here except the input flattening in cafex
 """
 import math
 
+import os
+
 import numpy as np
 import pytest
 
@@ -211,3 +213,34 @@ def test_golden_scores(oracle, golden, name):
         if "family_lnl" in e:
             assert np.abs(fam / np.array(e["family_lnl"]) - 1).max() <= TIGHT
     assert rel_err(v, e["neg_lnl"]) <= TIGHT, (v, e["neg_lnl"])
+
+
+def test_gamma_zero_sum_rule_at_the_edge_of_fp64(oracle):
+    """gamma_core.cpp:152 rejects a call when a category's root vector sums to exactly 0.  tests/golden/ref_borderline.json
+    holds the REAL reference on both sides of that edge (family `border`: at lambda 0.00085 the slowest category's largest
+    root entry is 5 denormal units, at 0.0008 it is 0): the restatement must classify every case alike and reproduce the
+    finite values."""
+    import json
+    from helpers import read
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_borderline.json")))
+    tree = P.parse_newick(read(g["args"]["tree"]))
+    species, ids, counts = P.read_family_table(read(g["args"]["families"]))
+    pb = P.build_problem(tree, species, ids, counts)
+    probs, mult = oracle.discrete_gamma(g["args"]["k"], g["args"]["alpha"])
+    seen_inf = seen_denormal = False
+    for lam, e in g["cases"].items():
+        pr = P.Params(lambdas=np.array([float(lam)]), prior=P.prior_uniform(pb.max_root_family_size), multipliers=mult, cat_probs=probs)
+        want = float(e["neg_lnl"])
+        got = oracle.score(pb, pr)
+        if np.isinf(want):
+            assert got == want
+            seen_inf = True
+            continue
+        assert abs(got - want) <= 1e-12 * abs(want)
+        _, cat, fam = oracle.score_gamma(pb, pr, per_family=True)
+        wc = np.array(e["category_likelihood"], dtype=float).reshape(cat.shape)
+        big = wc > 1e-290
+        assert np.allclose(cat[big], wc[big], rtol=1e-10)
+        assert np.all((cat[~big] == 0) == (wc[~big] == 0)) or np.all(np.abs(cat[~big] - wc[~big]) <= 1e-320)    # denormal range: few bits
+        seen_denormal = seen_denormal or bool(np.any((wc > 0) & (wc < 2.3e-308)))
+    assert seen_inf and seen_denormal
