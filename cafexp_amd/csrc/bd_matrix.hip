@@ -14,9 +14,13 @@
 // (probability.cpp:145).
 //
 // Mapping: ONE 64-lane wave per matrix.  Lane l owns E consecutive columns of the current row
-// in registers; a row step is E local FMAs, a 6-step Kogge-Stone scan over the 64 lane
-// aggregates with the constant ratio a^E (DPP/permute shuffles, no LDS, no barrier), and E
-// fix-up FMAs.  The row steps are sequential; the grid has one wave per (branch, category)
+// in registers; a row step is E local FMAs, a scan over the 64 lane aggregates with the constant
+// ratio a^E, and E fix-up FMAs.  The scan runs on DPP moves only (no LDS crossbar, no barrier):
+// four Kogge-Stone steps inside each row of 16 lanes (row_shr:1,2,4,8), then the row totals are
+// carried over with row_bcast:15 and row_bcast:31 times a per-lane power of the ratio; the
+// neighbour values (last column of the lane to the left, the carry) are wave_shr:1.  A row step is
+// a dependent chain, so its latency is the kernel's time until the HBM write of the pool takes
+// over (__shfl_up, which compiles to ds_bpermute, made a step of N = 751 take 2.5 us).  The row steps are sequential; the grid has one wave per (branch, category)
 // matrix, so a call with hundreds of matrices fills the chip.  Bound: HBM write of the pool.
 //
 // Two output layouts:
@@ -30,6 +34,16 @@
 #include "cafe_kernels.h"
 
 namespace cafe {
+
+// DPP move of a double (two 32-bit halves); lanes without a source read 0
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_move(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
+constexpr int kDppWaveShr1 = 0x138, kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
 
 template <int E, bool KMAJOR>
 __device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, const SlotParam sp, int slot) {
@@ -48,10 +62,13 @@ __device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, cons
     apow[0] = a;
 #pragma unroll
     for (int i = 1; i < E; ++i) apow[i] = apow[i - 1] * a;
-    double ratio[6];                     // (a^E)^(2^d)
+    double ratio[4];                     // (a^E)^(2^d): the in-row scan steps
     ratio[0] = apow[E - 1];
 #pragma unroll
-    for (int d = 1; d < 6; ++d) ratio[d] = ratio[d - 1] * ratio[d - 1];
+    for (int d = 1; d < 4; ++d) ratio[d] = ratio[d - 1] * ratio[d - 1];
+    // what a lane of rows 1, 3 (rows 2, 3) adds of the total that lane 15 of the row before (lane 31) holds
+    const double w15 = pow(apow[E - 1], (double)((lane & 15) + 1));
+    const double w31 = lane >= 32 ? pow(apow[E - 1], (double)(lane - 31)) : 0.0;
 
     double p[E];                         // P[row][c0 + i]
     double p0 = 1.0;                     // P[row][0] = a^row (k-major only: lane 0's left neighbour)
@@ -95,20 +112,20 @@ __device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, cons
             store_row(r, z);
             continue;
         }
-        double left = __shfl_up(p[E - 1], 1);
+        double left = dpp_move<kDppWaveShr1>(p[E - 1]);
         if (lane == 0) left = KMAJOR ? p0 : 0.0;
         double h[E];
         h[0] = left;
 #pragma unroll
         for (int i = 1; i < E; ++i) h[i] = fma(a, h[i - 1], p[i - 1]);
         double S = h[E - 1];             // inclusive scan of the lane totals with ratio a^E
-#pragma unroll
-        for (int d = 0; d < 6; ++d) {
-            double up = __shfl_up(S, 1 << d);
-            if (lane >= (1 << d)) S = fma(ratio[d], up, S);
-        }
-        double carry = __shfl_up(S, 1);
-        if (lane == 0) carry = 0.0;
+        S = fma(ratio[0], dpp_move<kDppRowShr1>(S), S);          // lanes without a source add ratio * 0
+        S = fma(ratio[1], dpp_move<kDppRowShr2>(S), S);
+        S = fma(ratio[2], dpp_move<kDppRowShr4>(S), S);
+        S = fma(ratio[3], dpp_move<kDppRowShr8>(S), S);
+        S = fma(w15, dpp_move<kDppRowBcast15, 0xa>(S), S);       // rows 1 and 3 take the total of rows 0 and 2
+        S = fma(w31, dpp_move<kDppRowBcast31, 0xc>(S), S);       // rows 2 and 3 take the total of rows 0..1
+        const double carry = dpp_move<kDppWaveShr1>(S);          // lane 0: 0
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             double hh = fma(apow[i], carry, h[i]);

@@ -122,14 +122,15 @@ struct cafe_ctx {
     // launch
     int n_cu = 0;                            // compute units of the device (K2's persistent grid)
     long stamps_launch = -1;                 // CAFE_GEMM_STAMPS_LAUNCH, read once at cafe_create
-    // A call's enqueue sequence is fixed per (reduction, K): upload, K1, the schedule, K4.  It is captured once in a
-    // hipGraph and replayed (one launch call instead of ~40 to ~300); the stream path remains for profiling runs.
+    // A call's enqueue sequence is fixed per (reduction, K): upload, K1, the schedule, K4.  It can be captured once in a
+    // hipGraph and replayed (one launch call instead of ~40 to ~300).  Off by default: on ROCm 7.2 the replay measured no
+    // faster than the stream enqueue at the mammals size (base 0.47 vs 0.48 ms) and slower with K = 4 (0.62 vs 0.41 ms).
     struct CallGraph {
         hipGraphExec_t exec = nullptr;
         cafe_stats stats{};                  // the work counters of the captured sequence
     };
     std::map<int, CallGraph> graphs;
-    int use_graph = 1;
+    int use_graph = 0;
 
     // measurement
     int profile = 0;

@@ -482,7 +482,7 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
         c->n_cu = prop.multiProcessorCount;
         const char* sl = std::getenv("CAFE_GEMM_STAMPS_LAUNCH");       // diagnostics: read once, never on the call path
         c->stamps_launch = sl ? std::atol(sl) : -1;
-        if (std::getenv("CAFE_NO_GRAPH")) c->use_graph = 0;
+        if (std::getenv("CAFE_USE_GRAPH")) c->use_graph = 1;
     }
 
     // outputs

@@ -228,11 +228,12 @@ int cafe_get_matrix(cafe_ctx* ctx, int32_t node, int32_t category, double* out, 
 int cafe_get_root_likelihoods(cafe_ctx* ctx, int64_t family, int32_t category, double* out, size_t out_len);
 int cafe_get_stats(const cafe_ctx* ctx, cafe_stats* stats);
 int cafe_matrix_size(const cafe_ctx* ctx);
-/* 1: bracket the phases and every K2 launch with HIP events so that cafe_stats.ms_* are measured (bench.py does); such
- * calls are enqueued launch by launch.  0 (default): no events, and the call's fixed launch sequence is captured once
- * per (model, K) in a hipGraph and replayed. */
+/* 1: bracket the phases and every K2 launch with HIP events so that cafe_stats.ms_* are measured (bench.py does).
+ * 0 (default): no events. */
 int cafe_set_profiling(cafe_ctx* ctx, int on);
-/* 0: never use hipGraphs (also: environment CAFE_NO_GRAPH at cafe_create); 1 (default): as described above. */
+/* 1: capture the call's fixed launch sequence once per (model, K) in a hipGraph and replay it (not while profiling);
+ * 0 (default; environment CAFE_USE_GRAPH at cafe_create turns it on): enqueue launch by launch.  Same kernels, same
+ * arguments, same bits; which is faster depends on the runtime. */
 int cafe_set_graphs(cafe_ctx* ctx, int on);
 /* diagnostic: K2's row tile is 16*mi rows, mi = 4..9, normally chosen per launch; mi forces one, 0 restores the choice */
 int cafe_debug_force_tile(cafe_ctx* ctx, int mi);

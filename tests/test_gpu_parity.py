@@ -434,13 +434,14 @@ def test_partial_api_on_torch_stream(capi, oracle):
 # ------------------------------------------------------------------ round 2: graphs, gathered-factor epilogue, multi-GPU entry points
 @pytest.mark.parametrize("name", ["mammals_base_l0.01", "mammals_gamma_k4_a2", "mammals_multilambda_err"])
 def test_graph_replay_equals_stream_enqueue(capi, oracle, golden, name):
-    """A call's launch sequence is captured once per (model, K) in a hipGraph and replayed; with graphs switched off (or
-    profiling on) the same sequence is enqueued launch by launch.  Same kernels, same arguments: the same bits -- also
+    """A call's launch sequence can be captured once per (model, K) in a hipGraph and replayed; with graphs off (the default)
+    or profiling on the same sequence is enqueued launch by launch.  Same kernels, same arguments: the same bits -- also
     when the parameters change between replays (they travel through the uploaded block, not through kernel arguments)."""
     e = golden["scores"][name]
     pb, pr, alpha = case_from_args(e["args"], oracle)
     K = 0 if pr.multipliers is None else len(pr.multipliers)
     g = capi.Context(pb, max_categories=max(1, K))
+    g.set_graphs(True)
     s = capi.Context(pb, max_categories=max(1, K))
     s.set_graphs(False)
     import dataclasses
