@@ -729,7 +729,9 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
         c->last_chunk_f0 = f0;
         c->last_chunk_nf = r.nf;
     }
-    HIP_TRY(c, launch_final_sum(c->d_fam_out, c->d_weights, c->d_failed, c->F_uniq, c->d_scratch, c->n_scratch, d_out, s));
+    // (the pair also goes straight into pinned host memory: cafe_score without a communicator reads it there after the
+    // stream has drained, no device-to-host copy)
+    HIP_TRY(c, launch_final_sum(c->d_fam_out, c->d_weights, c->d_failed, c->F_uniq, c->d_scratch, c->n_scratch, d_out, c->h_result, s));
     if (events) { HIP_TRY(c, hipEventRecord(c->ev[3], s)); c->events_valid = true; }
     return CAFE_OK;
 }
@@ -931,7 +933,10 @@ int cafe_score(cafe_ctx* ctx, const cafe_params* params, double* neg_lnl, const 
     if (rc != CAFE_OK) return rc;
     rc = comm_allreduce_pair(ctx, ctx->d_result, ctx->stream);          // family shards on other GPUs: one RCCL all-reduce
     if (rc != CAFE_OK) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    // without a communicator K4's last kernel has already written the pair to h_result (a host-only rejection went
+    // through a copy into d_result instead)
+    if (ctx->comm || ctx->last_rejected)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->upload_pending = false;
     *neg_lnl = cafe_finish_partial(ctx->h_result);

@@ -135,9 +135,9 @@ hipError_t launch_prune_gemm(const GemmArgs& a, int n_categories, int n_cu, hipS
 int prune_gemm_pick_mi(int rows, int n_col_tiles, int n_categories, int slots);     // row-tile height (in 16-row blocks)
 hipError_t launch_leaf_gather(const GatherArgs& a, int n_categories, hipStream_t stream);
 hipError_t launch_root_reduce(const ReduceArgs& a, hipStream_t stream);
-// sum_f w_f * fam_out[f] and the number of failed families -> out[0], out[1]
+// sum_f w_f * fam_out[f] and the number of failed families -> out[0], out[1] (and out_host[0..1] when not null: pinned host memory)
 hipError_t launch_final_sum(const double* fam_out, const double* weights, const int32_t* failed, int64_t n,
-                            double* scratch, int n_scratch, double* out, hipStream_t stream);
+                            double* scratch, int n_scratch, double* out, double* out_host, hipStream_t stream);
 hipError_t launch_mfma_probe(double* d_out, int iters, int blocks, hipStream_t stream);
 int bd_matrix_max_order();
 

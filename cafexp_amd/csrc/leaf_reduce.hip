@@ -408,7 +408,8 @@ __global__ __launch_bounds__(256) void partial_sum_kernel(const double* __restri
     }
 }
 
-__global__ __launch_bounds__(64) void fold_sum_kernel(const double* __restrict__ scratch, int n, double* out) {
+// out2: optionally a second copy, in host memory the device can write (the scorer's return value without a copy engine hop)
+__global__ __launch_bounds__(64) void fold_sum_kernel(const double* __restrict__ scratch, int n, double* out, double* out2) {
     if (threadIdx.x != 0) return;
     double s = 0.0, b = 0.0;
     for (int i = 0; i < n; ++i) {
@@ -417,17 +418,18 @@ __global__ __launch_bounds__(64) void fold_sum_kernel(const double* __restrict__
     }
     out[0] = s;
     out[1] = b;
+    if (out2) { out2[0] = s; out2[1] = b; }
 }
 
 hipError_t launch_final_sum(const double* fam_out, const double* weights, const int32_t* failed, int64_t n,
-                            double* scratch, int n_scratch, double* out, hipStream_t stream) {
+                            double* scratch, int n_scratch, double* out, double* out_host, hipStream_t stream) {
     int blocks = (int)((n + 255) / 256);
     if (blocks > n_scratch) blocks = n_scratch;
     if (blocks < 1) blocks = 1;
     (void)hipGetLastError();
     hipLaunchKernelGGL(partial_sum_kernel, dim3(blocks), dim3(256), 0, stream, fam_out, weights, failed, n, scratch);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(fold_sum_kernel, dim3(1), dim3(64), 0, stream, scratch, blocks, out);
+    hipLaunchKernelGGL(fold_sum_kernel, dim3(1), dim3(64), 0, stream, scratch, blocks, out, out_host);
     return hipGetLastError();
 }
 

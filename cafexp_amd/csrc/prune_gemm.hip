@@ -454,8 +454,11 @@ hipError_t launch_prune_gemm(const GemmArgs& a_in, int n_categories, int n_cu, h
         a.mi = prune_gemm_pick_mi(a.rows, a.n_col_tiles, n_categories, blocks);
         a.n_row_tiles = (a.rows + 16 * a.mi - 1) / (16 * a.mi);
     }
-    const int64_t tiles = (int64_t)n_categories * a.n_col_tiles * a.n_row_tiles;
-    if (tiles < blocks) blocks = (int)((tiles + 7) / 8 * 8);
+    // XCD x (blocks x, x+8, ...) owns the (category, column tile) pairs x, x+8, ... and its blocks share those pairs' row
+    // tiles: a small launch needs ceil(pairs / 8) * n_row_tiles blocks PER XCD or the owning XCD's few blocks walk the row
+    // tiles one after the other while the other XCDs' blocks have nothing to do
+    const int64_t per_xcd = (((int64_t)n_categories * a.n_col_tiles + 7) / 8) * a.n_row_tiles;
+    if (per_xcd * 8 < blocks) blocks = (int)(per_xcd * 8);
     dim3 grid(blocks, 1, 1);
     (void)hipGetLastError();
     switch (a.mi) {
