@@ -50,7 +50,11 @@ constexpr int a_stride(int bm) { return (bm % 32 == 16) ? bm : bm + 16; }
 // without an assemble pass.  TRANS: a factor GEMM (plain store over the CHILD's columns) writes its result transposed,
 // F_T[column][16 - out_off + panel row] with the rows contiguous: whoever spreads that factor over the parent's columns
 // (K3's assemble pass, the LEAF == 2 epilogue) then fetches whole 128-byte lines per mapped column instead of one
-// 8-byte element per line.  The +16 puts every 16-row block of the tile on a line boundary.
+// 8-byte element per line.  The +16 puts every 16-row block of the tile on a line boundary.  Such a launch issues its
+// MFMAs with the two operands swapped: the fragments of v_mfma_f64_16x16x4_f64 are symmetric (16 along lane & 15, 4
+// along lane >> 4), so D' = B^T A^T = C^T lands in the accumulators -- lane & 15 is then the ROW of C and (lane >> 4) + 4
+// reg its column, and a store instruction writes four columns x 16 consecutive rows = four full 128-byte lines of the
+// transposed factor, as wide as the row-major store of the other variants (32-byte pieces measured 8 % slower).
 template <int MI, bool MUL, int LEAF, bool TRANS = false>
 __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the body uses amdgcn-only types (buffer resource); hipcc's host pass only needs the stub
@@ -214,8 +218,13 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
                 if (pre) read_b(src, ns, bfr[(s4 + 1) & 1]);
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
-                    acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bfr[s4 & 1][0], acc[i][0], 0, 0, 0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bfr[s4 & 1][1], acc[i][1], 0, 0, 0);
+                    if (TRANS) {                            // operands swapped: the accumulators hold C^T
+                        acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfr[s4 & 1][0], af[i], acc[i][0], 0, 0, 0);
+                        acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfr[s4 & 1][1], af[i], acc[i][1], 0, 0, 0);
+                    } else {
+                        acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bfr[s4 & 1][0], acc[i][0], 0, 0, 0);
+                        acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bfr[s4 & 1][1], acc[i][1], 0, 0, 0);
+                    }
                     if (pre) af[i] = src[a_off + ns * 4 * SA + i * 16];
                     __builtin_amdgcn_sched_barrier(0);      // keep "two MFMAs, then the read that reuses their register"
                 }
@@ -240,8 +249,13 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
                     read_b(base, s4, bfr[0]);
 #pragma unroll
                     for (int i = 0; i < MI; ++i) {
-                        acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bfr[0][0], acc[i][0], 0, 0, 0);
-                        acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bfr[0][1], acc[i][1], 0, 0, 0);
+                        if (TRANS) {
+                            acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfr[0][0], af[i], acc[i][0], 0, 0, 0);
+                            acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfr[0][1], af[i], acc[i][1], 0, 0, 0);
+                        } else {
+                            acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bfr[0][0], acc[i][0], 0, 0, 0);
+                            acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bfr[0][1], acc[i][1], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -254,7 +268,8 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
         // All accesses are buffer operations: descriptor + SCALAR offset (row block, register row group, column
         // half) + one fixed per-lane offset -- no address VALU and no LDS round trip; the old panel values (MUL) and
         // the leaf factors (LEAF) of row block i+1 are loaded before block i is stored.
-        const unsigned c_voff = TRANS ? (unsigned)(((wave * 32 + l15) * ldt + l4) * 8) : (unsigned)((l4 * ldb + wave * 32 + l15) * 8);
+        // TRANS (accumulators hold C^T): lane & 15 = row inside the 16-row block, (lane >> 4) + 4 reg = column inside the 16
+        const unsigned c_voff = TRANS ? (unsigned)(((wave * 32 + l4) * ldt + l15) * 8) : (unsigned)((l4 * ldb + wave * 32 + l15) * 8);
         const int c_soff0 = TRANS ? (cur.col0 * ldt + cur.row0 + 16) * 8 : ((cur.row0 + a.out_off) * ldb + cur.col0) * 8;
         __amdgpu_buffer_rsrc_t rsL = cur.rsC;
         constexpr int NT = LEAF == 3 ? 3 : 1;               // taps of the leaf sibling: 1, or the 3 of an error model
@@ -319,13 +334,21 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int step = i * 16 + r * 4;
-                if (decltype(full)::value || step + l4 < rows_here) {
+                if (TRANS) {                                // C^T: register r = columns 4r + (lane >> 4), lanes = 16 rows
+                    if (decltype(full)::value || i * 16 + l15 < rows_here) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const double v = acc[i][j][r];      // (a bit_cast straight from the vector element stores element 0)
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(int2_t, v), cur.rsC, c_voff,
+                                                                  c_soff0 + ((j * 16 + r * 4) * ldt + i * 16) * 8, 0);
+                        }
+                    }
+                } else if (decltype(full)::value || step + l4 < rows_here) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         double v = acc[i][j][r];
                         if (MUL || LEAF) v *= p.f[j][r];
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(int2_t, v), cur.rsC, c_voff,
-                                                              c_soff0 + (TRANS ? (j * 16 * ldt + step) * 8 : (step * ldb + j * 16) * 8), 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(int2_t, v), cur.rsC, c_voff, c_soff0 + (step * ldb + j * 16) * 8, 0);
                     }
                 }
             }
