@@ -96,6 +96,10 @@ __global__ __launch_bounds__(256) void simulate_kernel(const SimArgs a) {
                 uint32_t r[4];
                 philox4x32_10((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)v, 0u, a.k0, a.k1, r);
                 const double u = ((double)(((uint64_t)r[0] << 21) ^ (r[1] >> 11)) + 0.5) * (1.0 / 9007199254740992.0);   // (0,1)
+                // A saturated / degenerate branch has an all-zero row (matrix_cache.cpp:153): target = 0 and the search
+                // returns size 0.  The reference draws from std::discrete_distribution over all-zero weights there
+                // (probability.cpp:333-344, after a uniform draw it then discards) -- outside that distribution's
+                // precondition (sum of weights > 0); libstdc++ returns index 0, so does this path, by construction.
                 const double target = u * row[a.M - 1];     // sizes 0..M-1 carry the weights (:338-341)
                 int lo = 0, hi = a.M - 1;                   // first c with cdf[c] >= target
                 while (lo < hi) {

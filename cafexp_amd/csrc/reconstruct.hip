@@ -209,6 +209,10 @@ struct DevBuf {
 
 }  // namespace
 
+// (The reference's "Zero matrix found" throw, gene_family_reconstructor.cpp:87, cannot fire: matrix::is_zero tests the
+// largest entry, and precalculate_matrices always sets P[0][0] = 1, matrix_cache.cpp:148 -- saturated matrices included.
+// A saturated branch reconstructs through its all-zero rows exactly as the reference does: every product is 0 and the
+// first argmax wins.)
 int reconstruct_impl(cafe_ctx* c, const cafe_params* pr, const float* root_prior, int32_t* states) {
     if (!pr || !pr->lambdas || !root_prior || !states) { set_err(c, "cafe_reconstruct: lambdas, root_prior and states are required"); return CAFE_ERR_ARGUMENT; }
     const bool gamma = pr->model == CAFE_MODEL_GAMMA;
