@@ -85,6 +85,8 @@ def make_reconstruct():
         "mammals_lambda_tree": dict(tree=T, families=F, limit=100, lambdas="0.01,0.05", lambda_tree=data("chimphuman_separate_lambda.txt")),
         "mammals_poisson": dict(tree=T, families=F, limit=60, prior="poisson:10", **{"lambda": 0.01}),
         "synth20": dict(tree=data("synth20_tree.txt"), families=data("synth20_families.txt"), **{"lambda": 0.004}),
+        # lambda * t > 1 on the longest branch (96.4): that matrix is saturated, rows s >= 1 all zero (matrix_cache.cpp:153)
+        "mammals_saturated": dict(tree=T, families=F, limit=60, **{"lambda": 0.012}),
     }
     out = {"generator": "tests/golden/make_golden.py reconstruct", "source": "oracle/_ref/ref_harness reconstruct (real reference)", "cases": {}}
     for name, kv in jobs.items():

@@ -8,23 +8,27 @@ set -e
 R=$PWD
 OUT=$R/gpurun_out
 mkdir -p $OUT
-rm -rf $OUT/prof $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
+rm -rf $OUT/prof $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/prof_mammals
 cd /tmp && export TMPDIR=/tmp
-echo "[1/5] bench with cpu_baseline"
-timeout -k 10 500 python3 $R/bench.py --steps 5 --warmup 2 > $OUT/bench_full.json 2> $OUT/bench_full.err
-echo "[2/5] kernel trace"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof -o run --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/prof.log 2>&1
-echo "[3/5] pmc FETCH_SIZE"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o run --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
-echo "[4/5] pmc WRITE_SIZE"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o run --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
-echo "[5/5] pmc SQ"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o run --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1
+echo "[1/8] bench with cpu_baseline, parity sample, one column per family, other configs"
+timeout -k 10 600 python3 $R/bench.py --steps 5 --warmup 2 > $OUT/bench_full.json 2> $OUT/bench_full.err
+echo "[2/8] kernel trace"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof -o run --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $OUT/prof.log 2>&1
+echo "[3/8] pmc FETCH_SIZE"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o run --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/pmc_fetch.log 2>&1
+echo "[4/8] pmc WRITE_SIZE"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o run --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/pmc_write.log 2>&1
+echo "[5/8] pmc SQ"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o run --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/pmc_sq.log 2>&1
+echo "[6/8] mammals calls (BASELINE configs 2, 3)"
+timeout -k 10 200 python3 $R/tools/mammals_calls.py 300 > $OUT/mammals_calls.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_mammals -o run --output-format csv -- python3 $R/tools/mammals_calls.py 100 > $OUT/prof_mammals.log 2>&1
 # the per-dispatch traces are large; keep what the summaries need
-find $OUT/prof -name "*kernel_trace.csv" -delete
-tail -1 $OUT/bench_full.json
-echo "[6] reconstruction kernels at the bench shape"
-rm -rf $OUT/prof_recon
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_recon -o run --output-format csv -- python3 $R/tools/reconstruct_scale.py 50000 > $OUT/prof_recon.log 2>&1
-find $OUT/prof_recon -name "*kernel_trace.csv" -delete
-grep "reconstruct:" $OUT/prof_recon.log | tail -1
+find $OUT/prof $OUT/prof_mammals -name "*kernel_trace.csv" -delete
+cd $R
+tail -1 $OUT/bench_full.json | cut -c1-300
+echo "[7/8] eight shards, one after the other (what each rank of an 8-GPU run does)"
+bash tools/shard_rehearsal.sh 8 | tail -1
+echo "[8/8] the launcher path: python bench.py --gpus 2 (gloo rehearsal, both ranks on this GPU)"
+timeout -k 10 300 python3 bench.py --gpus 2 --backend gloo --steps 3 --no-cpu-baseline > $OUT/bench_gloo2.json 2> $OUT/bench_gloo2.err
+cut -c1-200 $OUT/bench_gloo2.json
