@@ -60,6 +60,20 @@ def test_binding_sources_use_no_private_reference_members():
     assert "get_lambda_index(" not in code
 
 
+def test_integration_md_quotes_the_compiled_binding():
+    """INTEGRATION.md section 2 shows the reference-side binding: every ```cpp block there must be text of
+    integration/hip_models.{h,cpp}, the files `make -C oracle ref_hip` compiles against the reference's headers."""
+    import re
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    src = open(os.path.join(ROOT, "integration", "hip_models.cpp")).read() + open(os.path.join(ROOT, "integration", "hip_models.h")).read()
+    norm = lambda t: re.sub(r"\s+", " ", t).strip()
+    blocks = re.findall(r"```cpp\n(.*?)```", md, flags=re.S)
+    assert len(blocks) >= 4
+    src_n = norm(src)
+    for b in blocks:
+        assert norm(b) in src_n, b[:200]
+
+
 needs_harness = pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/ref_hip_harness is built in the container only (make -C oracle ref_hip)")
 
 
