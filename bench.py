@@ -292,7 +292,7 @@ def main():
     for _ in range(args.warmup):
         value = step()
     fence()
-    flops = flops_fam = ms_gemm = 0.0
+    flops = flops_fam = flops_dense = ms_gemm = 0.0
     launches = 0
     ms_mat = ms_prune = 0.0
     t0 = time.perf_counter()
@@ -300,6 +300,7 @@ def main():
         value = step()
         st = ctx.stats()                              # HIP events of this call, recorded on the launch stream
         flops += st["gemm_flops"]; flops_fam += st["gemm_flops_per_family"]; ms_gemm += st["ms_gemm"]; launches += st["gemm_launches"]
+        flops_dense += st["gemm_flops_dense"]
         ms_mat += st["ms_matrices"]; ms_prune += st["ms_prune"]
     fence()
     elapsed = time.perf_counter() - t0
@@ -337,8 +338,10 @@ def main():
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": "prune_gemm_kernel", "launches_per_step": launches // max(1, args.steps),
                          "avg_launch_ms": ms_gemm / max(1, launches), "flops_per_launch": flops / max(1, launches),
-                         # columns = distinct subtree patterns: the flops the launches execute; with
-                         # one column per family at every node (SURVEY 8d's per-family figure) they would be:
+                         # flops_per_launch = what the launches EXECUTE: columns = distinct subtree patterns, K tiles = those
+                         # inside a row tile's non-zero extent (DESIGN.md sections 2, 3).  With every K tile of those
+                         # columns, and with one column per family at every node (SURVEY 8d's per-family figure):
+                         "flops_per_launch_all_k_tiles": flops_dense / max(1, launches),
                          "flops_per_launch_one_column_per_family": flops_fam / max(1, launches)},
             "phases_ms_per_step": {"bd_matrix_build": ms_mat / args.steps, "prune_total": ms_prune / args.steps,
                                    "prune_gemm": ms_gemm / args.steps},

@@ -55,6 +55,7 @@ class CafeStats(C.Structure):
         ("gemm_launches", C.c_int64), ("n_matrices", C.c_int64), ("n_unique_families", C.c_int64),
         ("n_chunks", C.c_int64), ("matrix_bytes", C.c_int64), ("panel_bytes", C.c_int64),
         ("n_assemble_passes", C.c_int64), ("n_gather_epilogues", C.c_int64), ("n_leaf_passes", C.c_int64),
+        ("gemm_flops_dense", C.c_double),
     ]
 
     def as_dict(self):

@@ -92,9 +92,33 @@ __device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, cons
 #pragma unroll
     for (int i = 0; i < E; ++i) z[i] = 0.0;
 
+    // k-major: the non-zero extent (first / last contraction index) of every block of 16 stored columns, for K2
+    __shared__ int ext_lo[128], ext_hi[128];
+    int first_nz = 0x7fffffff, last_nz = -1;          // over this lane's columns
+    auto note = [&](int r, const double* v) {
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < E; ++i) any = any || (c0 + i < n && v[i] != 0.0);
+        if (any) { first_nz = first_nz < r ? first_nz : r; last_nz = r; }
+    };
+    auto publish_extents = [&]() {
+        if (!KMAJOR || !pool.ext) return;
+        const int nb = pool.ext_blocks;
+        for (int b = lane; b < nb; b += 64) { ext_lo[b] = 0x7fffffff; ext_hi[b] = -1; }
+        __syncthreads();                               // one wave per block: orders the LDS initialisation
+        if (last_nz >= 0 && j0 < n - 1) {
+            const int b_lo = j0 >> 4, b_hi = min(j0 + E - 1, n - 2) >> 4;
+            for (int b = b_lo; b <= b_hi && b < nb; ++b) { atomicMin(&ext_lo[b], first_nz); atomicMax(&ext_hi[b], last_nz); }
+        }
+        __syncthreads();
+        int32_t* out = pool.ext + (int64_t)slot * nb * 2;
+        for (int b = lane; b < nb; b += 64) { out[2 * b] = ext_lo[b]; out[2 * b + 1] = ext_hi[b]; }
+    };
+
     if (sp.zero) {                       // saturated / degenerate: every entry with parent size >= 1 is 0
         if (!KMAJOR) store_row(0, p);    // row-major keeps P's row 0 = e_0; k-major never holds it
         for (int r = KMAJOR ? 0 : 1; r < n_rows; ++r) store_row(r, z);
+        publish_extents();               // all blocks empty
         return;
     }
 
@@ -103,6 +127,7 @@ __device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, cons
 #pragma unroll
         for (int i = 0; i < E; ++i) v[i] = pow(a, (double)(c0 + i));
         store_row(0, v);
+        note(0, v);
     } else {
         store_row(0, p);
     }
@@ -143,10 +168,12 @@ __device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, cons
                 v[i] = t < 1.0 ? t : 1.0;
             }
             store_row(r, v);
+            note(r, v);
         } else {
             store_row(r, p);
         }
     }
+    publish_extents();
 }
 
 template <int E, bool KMAJOR>

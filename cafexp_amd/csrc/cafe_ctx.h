@@ -133,6 +133,9 @@ struct cafe_ctx {
     int use_graph = 0;
 
     // measurement
+    struct GemmLaunch { int child; int rows; int64_t cols; int K; };   // what collect_stats needs to count executed flops
+    std::vector<GemmLaunch> gemm_launches_info;
+    bool stats_flops_stale = false;           // gemm_flops still holds the dense count of the last profiled call
     int profile = 0;
     int force_mi = 0;                        // diagnostic: K2 row-tile height for every launch (0 = chosen per launch)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -275,7 +275,7 @@ void free_device(cafe_ctx* c) {
     comm_release(c);
     for (auto& g : c->graphs) if (g.second.exec) hipGraphExecDestroy(g.second.exec);
     c->graphs.clear();
-    hipFree(c->d_counts); hipFree(c->d_weights); hipFree(c->pool.base); hipFree(c->kpool.base); hipFree(c->d_params); hipFree(c->d_panels);
+    hipFree(c->d_counts); hipFree(c->d_weights); hipFree(c->pool.base); hipFree(c->kpool.base); hipFree(c->kpool.ext); hipFree(c->d_params); hipFree(c->d_panels);
     hipFree(c->d_fam_out); hipFree(c->d_fam_lik); hipFree(c->d_cat_out); hipFree(c->d_failed);
     hipFree(c->d_scratch); hipFree(c->d_result); hipFree(c->d_stamps);
     for (auto ptr : c->d_edge_map) hipFree(ptr);
@@ -434,6 +434,7 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     c->kpool.kmajor = 1;
     c->kpool.ld = round_up(c->N - 1, 16) + round_up(kMaxBM, 16) + 16;     // a row tile may start at any valid row
     c->kpool.stride = (int64_t)c->kc * c->kpool.ld;
+    c->kpool.ext_blocks = (c->N - 1 + 15) / 16;
     c->max_kslots = c->n_pairs[1] * c->Kmax;
     c->slot_of.assign((size_t)c->n_nodes * c->Kmax, -1);
     for (int v = 0; v < c->n_nodes; ++v) {
@@ -451,6 +452,10 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     // padding columns / rows of both layouts are never written by K1 and must read as 0
     HIP_TRY(c, hipMemset(c->pool.base, 0, pool_bytes));
     HIP_TRY(c, hipMemset(c->kpool.base, 0, kpool_bytes));
+    // non-zero extents of the k-major matrices (K1 writes them, K2 skips the K tiles outside them)
+    HIP_TRY(c, hipMalloc(&c->kpool.ext, sizeof(int32_t) * 2 * (size_t)std::max(1, c->max_kslots) * c->kpool.ext_blocks));
+    HIP_TRY(c, hipMemset(c->kpool.ext, 0, sizeof(int32_t) * 2 * (size_t)std::max(1, c->max_kslots) * c->kpool.ext_blocks));
+    if (std::getenv("CAFE_NO_KSKIP")) { (void)hipFree(c->kpool.ext); c->kpool.ext = nullptr; }    // diagnostic: every K tile of every launch
     c->stats.matrix_bytes = (int64_t)(pool_bytes + kpool_bytes);
 
     // per-call parameter block (layout: cafe_ctx.h), device + pinned mirror
@@ -640,7 +645,7 @@ bool rejected(const cafe_ctx* c, const cafe_params* pr, int K) {
 // K1, the schedule (K2 / K3 launches), K4, the final sum into d_out.  Everything that changes between calls of the
 // same shape travels through the parameter block; kernel arguments depend only on (reduction, K, error model).
 int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, double* d_out, hipStream_t s, bool events) {
-    c->stats.gemm_flops = c->stats.gemm_bytes = c->stats.gemm_flops_per_family = 0;
+    c->stats.gemm_flops = c->stats.gemm_bytes = c->stats.gemm_flops_per_family = c->stats.gemm_flops_dense = 0;
     c->stats.gemm_launches = 0;
     HIP_TRY(c, hipMemcpyAsync(c->d_params, c->h_stage, c->params_bytes, hipMemcpyHostToDevice, s));
     if (events) HIP_TRY(c, hipEventRecord(c->ev[0], s));
@@ -649,6 +654,7 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
 
     // ---- prune, chunk by chunk
     c->gemm_ev_used = 0;
+    c->gemm_launches_info.clear();
     for (int64_t f0 = 0; f0 < c->Fp; f0 += c->chunk_cols) {
         const int64_t cols = std::min<int64_t>(c->chunk_cols, c->Fp - f0);
         // columns (and leading dimension) of a node's panel: one per distinct leaf-count pattern under it, or the chunk
@@ -713,7 +719,9 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
                 HIP_TRY(c, launch_prune_gemm(g, K, c->n_cu, s));
                 if (events && c->gemm_ev_used + 1 <= c->gemm_ev.size()) HIP_TRY(c, hipEventRecord(c->gemm_ev[c->gemm_ev_used++], s));
                 c->stats.gemm_launches += 1;
-                c->stats.gemm_flops += 2.0 * rows * (c->M + 1) * (double)gc * K;
+                c->gemm_launches_info.push_back({op.child, g.rows, gc, K});
+                c->stats.gemm_flops_dense += 2.0 * rows * (c->M + 1) * (double)gc * K;
+                c->stats.gemm_flops += 2.0 * rows * (c->M + 1) * (double)gc * K;      // (replaced by the executed count in collect_stats)
                 c->stats.gemm_flops_per_family += 2.0 * rows * (c->M + 1) * (double)cols * K;
                 c->stats.gemm_bytes += 8.0 * K * ((double)rows * (c->M + 1) + (double)(c->M + 1) * gc + (double)rows * gc);
             }
@@ -732,7 +740,7 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
     // (the pair also goes straight into pinned host memory: cafe_score without a communicator reads it there after the
     // stream has drained, no device-to-host copy)
     HIP_TRY(c, launch_final_sum(c->d_fam_out, c->d_weights, c->d_failed, c->F_uniq, c->d_scratch, c->n_scratch, d_out, c->h_result, s));
-    if (events) { HIP_TRY(c, hipEventRecord(c->ev[3], s)); c->events_valid = true; }
+    if (events) { HIP_TRY(c, hipEventRecord(c->ev[3], s)); c->events_valid = true; c->stats_flops_stale = true; }
     return CAFE_OK;
 }
 
@@ -811,6 +819,7 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bo
         const int64_t n_mat = c->stats.n_matrices;
         c->stats.gemm_flops = cg.stats.gemm_flops; c->stats.gemm_bytes = cg.stats.gemm_bytes;
         c->stats.gemm_flops_per_family = cg.stats.gemm_flops_per_family; c->stats.gemm_launches = cg.stats.gemm_launches;
+        c->stats.gemm_flops_dense = cg.stats.gemm_flops_dense;
         c->stats.n_matrices = n_mat;
         c->last_chunk_f0 = (c->Fp - 1) / c->chunk_cols * c->chunk_cols;
         c->last_chunk_nf = std::max<int64_t>(0, std::min<int64_t>(c->chunk_cols, c->F_uniq - c->last_chunk_f0));
@@ -833,6 +842,34 @@ void collect_stats(cafe_ctx* c) {
     for (size_t i = 0; i + 1 < c->gemm_ev_used; i += 2)
         if (hipEventElapsedTime(&ms, c->gemm_ev[i], c->gemm_ev[i + 1]) == hipSuccess) g += ms;
     c->stats.ms_gemm = g;
+    // flops the K2 launches EXECUTED: K tiles outside a row tile's non-zero extent are skipped, so read the extents K1
+    // published for this call and count, per launch, what its row tiles ran (same tile height as the launcher picks)
+    if (c->kpool.ext && !c->gemm_launches_info.empty() && c->stats_flops_stale) {
+        const int nb = c->kpool.ext_blocks;
+        std::vector<int32_t> ext((size_t)2 * c->max_kslots * nb);
+        if (hipMemcpy(ext.data(), c->kpool.ext, ext.size() * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return;
+        const int n_k = (c->M + 1 + kBK - 1) / kBK;
+        double executed = 0;
+        for (const auto& L : c->gemm_launches_info) {
+            const int mi = c->force_mi ? c->force_mi : prune_gemm_pick_mi(L.rows, (int)(L.cols / kBN), L.K, 2 * c->n_cu / 8 * 8);
+            const int bm = 16 * mi;
+            for (int k = 0; k < L.K; ++k) {
+                const int32_t* e = ext.data() + (size_t)c->slot_of[(size_t)L.child * c->Kmax + k] * nb * 2;
+                for (int row0 = 0; row0 < L.rows; row0 += bm) {
+                    int lo = 0x7fffffff, hi = -1;
+                    for (int b = row0 / 16; b < row0 / 16 + mi && b < nb; ++b) { lo = std::min(lo, e[2 * b]); hi = std::max(hi, e[2 * b + 1]); }
+                    if (hi < lo) { lo = 0; hi = 0; }
+                    hi = std::min(hi, c->M);
+                    const int nkt = hi / kBK - lo / kBK + 1;
+                    const int kk = std::min(nkt * kBK, c->M + 1 - (lo / kBK) * kBK);      // the last K tile of the matrix is ragged
+                    executed += 2.0 * std::min(bm, L.rows - row0) * (double)kk * (double)L.cols;
+                    (void)n_k;
+                }
+            }
+        }
+        c->stats.gemm_flops = executed;
+        c->stats_flops_stale = false;
+    }
 }
 
 }  // namespace

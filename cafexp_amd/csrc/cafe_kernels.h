@@ -42,6 +42,12 @@ struct MatrixPool {
     int32_t rows;     // k-major: rows written
     int32_t k_valid;  // k-major: M+1
     int32_t kmajor;
+    // k-major only: per matrix and per block of 16 consecutive parent sizes (columns of Pt), the first and last
+    // contraction index c whose entries are not all exactly 0 -- ext[(slot * ext_blocks + block) * 2 + {0, 1}], written by
+    // K1 (first > last: the block is all zero).  Far from the diagonal the entries of a short branch underflow to exact
+    // zeros; K2 skips the K tiles that lie outside a row tile's extent (adding exact zeros changes no bit).
+    int32_t* ext;
+    int32_t ext_blocks;
 };
 
 // Likelihood panels: [category][row][family], family fastest, so that a node's panel is the

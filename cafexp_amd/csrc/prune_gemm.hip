@@ -118,7 +118,9 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
     struct Tile {
         __amdgpu_buffer_rsrc_t rsA, rsB, rsC;
         int cat, row0, col0, row_tile;
+        int kt0, nkt;                                       // K tiles [kt0, kt0 + nkt) hold this row tile's non-zero A entries
     };
+    const int32_t* __restrict__ ext = a.pool.ext;
     auto decode = [&](int t) -> Tile {
         Tile x;
         x.row_tile = t % a.n_row_tiles;
@@ -130,6 +132,23 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
         x.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.pool.base + (int64_t)a.slot[x.cat] * a.pool.stride), 0, (int)(a.pool.stride * 8), 0x00020000);
         x.rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src + (int64_t)x.cat * a.panel_kstride), 0, kbytes, 0x00020000);
         x.rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dst + (int64_t)x.cat * a.panel_kstride), 0, kbytes, 0x00020000);
+        // Extent of the contraction index over which this row tile's part of the matrix is not exactly zero (K1 records it
+        // per block of 16 rows): far from the diagonal the entries underflow to 0, and a K tile of zeros adds nothing --
+        // skipping it leaves every accumulator bit as it is and saves its MFMAs and the B rows it would have staged.
+        x.kt0 = 0;
+        x.nkt = n_k;
+        if (ext) {
+            const int b0 = x.row0 >> 4;
+            const int32_t* e = ext + ((int64_t)a.slot[x.cat] * a.pool.ext_blocks + b0) * 2;
+            int lo = 0x7fffffff, hi = -1;
+#pragma unroll
+            for (int b = 0; b < MI; ++b)
+                if (b0 + b < a.pool.ext_blocks) { lo = min(lo, e[2 * b]); hi = max(hi, e[2 * b + 1]); }
+            if (hi < lo) { lo = 0; hi = 0; }                // an all-zero tile still runs one K tile: the panel must receive its zeros
+            hi = min(hi, a.k_valid - 1);
+            x.kt0 = __builtin_amdgcn_readfirstlane(lo / kBK);
+            x.nkt = __builtin_amdgcn_readfirstlane(hi / kBK - lo / kBK + 1);
+        }
         return x;
     };
     // LDS-DMA fill of K tile k0 of output tile x into stage `buf`, quarter q (16 slots = 4 quarters x 4 waves).
@@ -158,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
     {
         const Tile first = decode(local);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) stage_quarter(first, 0, 0, q);
+        for (int q = 0; q < 4; ++q) stage_quarter(first, first.kt0 * kBK, 0, q);
     }
     int g = 0;                                              // running K-tile count: stage parity
     __syncthreads();                                        // vmcnt(0) + barrier: the first K tile has landed (later
@@ -196,12 +215,14 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
             for (int i = 0; i < MI; ++i) af[i] = base[a_off + i * 16];
             read_b(base, 0, bfr[0]);
         }
-        for (int kt = 0; kt + 1 < n_k; ++kt) {
+        const int nkt = cur.nkt, kbase = cur.kt0 * kBK;     // this tile's K tiles: kbase, kbase + 16, ...
+        const int steps_last = cur.kt0 + nkt == n_k ? last_steps : 4;   // only the matrix's last K tile is ragged
+        for (int kt = 0; kt + 1 < nkt; ++kt) {
             const int buf = g & 1;
             const double* base = lds + buf * STAGE;
             const double* nbase = lds + (buf ^ 1) * STAGE;
-            const int k1 = (kt + 1) * kBK;                  // K tile being staged into the other stage
-            const bool next_full = kt + 2 < n_k;            // K tile kt+1 is another pipelined one (not the ragged last)
+            const int k1 = kbase + (kt + 1) * kBK;          // K tile being staged into the other stage
+            const bool next_full = kt + 2 < nkt;            // K tile kt+1 is another pipelined one (not this tile's last)
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 if (s4 < 3) {
@@ -210,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
                 } else {
                     __syncthreads();                        // K tile kt+1 has landed; every wave has read all of K tile kt
                     if (next_full) stage_quarter(cur, k1 + kBK, buf, 0);
-                    else if (has_next) stage_quarter(nxt, 0, buf, 0);
+                    else if (has_next) stage_quarter(nxt, nxt.kt0 * kBK, buf, 0);
                 }
                 const bool pre = s4 < 3 || next_full;       // uniform
                 const double* src = s4 < 3 ? base : nbase;
@@ -236,14 +257,15 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
             const int buf = g & 1;
             const double* base = lds + buf * STAGE;
             if (has_next) {
-                if (n_k == 1) stage_quarter(nxt, 0, buf ^ 1, 0);
-                stage_quarter(nxt, 0, buf ^ 1, 1);
-                stage_quarter(nxt, 0, buf ^ 1, 2);
-                stage_quarter(nxt, 0, buf ^ 1, 3);
+                const int nk0 = nxt.kt0 * kBK;
+                if (nkt == 1) stage_quarter(nxt, nk0, buf ^ 1, 0);
+                stage_quarter(nxt, nk0, buf ^ 1, 1);
+                stage_quarter(nxt, nk0, buf ^ 1, 2);
+                stage_quarter(nxt, nk0, buf ^ 1, 3);
             }
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
-                if (s4 < last_steps) {
+                if (s4 < steps_last) {
 #pragma unroll
                     for (int i = 0; i < MI; ++i) af[i] = base[a_off + s4 * 4 * SA + i * 16];
                     read_b(base, s4, bfr[0]);

@@ -115,7 +115,9 @@ typedef struct cafe_stats {
     double ms_prune;                 /* K2 prune_gemm + K3 leaf_gather over all nodes */
     double ms_gemm;                  /* K2 only */
     double ms_reduce;                /* K4 root_reduce */
-    double gemm_flops;               /* algorithmic flops: sum over launches of 2*rows*(M+1)*columns, columns = the
+    double gemm_flops;               /* flops the K2 launches executed (profiling on): per row tile 2*rows*k*columns over the
+                                        K tiles inside the tile's non-zero extent (entries far from a short branch's
+                                        diagonal underflow to exact zeros; those K tiles are skipped), columns = the
                                         distinct subtree patterns the launch processes */
     double gemm_bytes;               /* algorithmic bytes of the same launches (P + B read, C written) */
     double gemm_flops_per_family;    /* the same sum with one column per (distinct) family at every node: SURVEY 8d's
@@ -130,6 +132,7 @@ typedef struct cafe_stats {
     int64_t n_assemble_passes;       /* K3 launches that spread factor panels of de-duplicated children over a parent's columns */
     int64_t n_gather_epilogues;      /* K2 launches that fold a sibling's factor panel into their epilogue instead */
     int64_t n_leaf_passes;           /* K3 launches with leaf children only (cherries, polytomies, error models) */
+    double gemm_flops_dense;         /* the same launches with every K tile: sum of 2*rows*(M+1)*columns */
 } cafe_stats;
 
 /* NULL on failure; err (optional, errlen bytes) receives the reason. */
