@@ -132,8 +132,15 @@ struct cafe_ctx {
     std::map<int, CallGraph> graphs;
     int use_graph = 0;
 
+    // K2's row-tile height per launch is chosen from the non-zero extents of the PREVIOUS call's matrices (K1 publishes
+    // them on the device; a copy lands in h_ext while the call's K2 launches run): the parameters of consecutive scorer
+    // calls are close, and the choice only affects speed, never a bit of the result
+    int32_t* h_ext = nullptr;                // pinned [max_kslots][ext_blocks][2]
+    bool h_ext_valid = false;
+    int h_ext_K = 0;                         // categories of the call the copy belongs to
+
     // measurement
-    struct GemmLaunch { int child; int rows; int64_t cols; int K; };   // what collect_stats needs to count executed flops
+    struct GemmLaunch { int child; int rows; int64_t cols; int K; int mi; };   // what collect_stats needs to count executed flops
     std::vector<GemmLaunch> gemm_launches_info;
     bool stats_flops_stale = false;           // gemm_flops still holds the dense count of the last profiled call
     int profile = 0;

@@ -282,6 +282,7 @@ void free_device(cafe_ctx* c) {
     for (auto ptr : c->d_leaf_cnt) hipFree(ptr);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_result) hipHostFree(c->h_result);
+    if (c->h_ext) hipHostFree(c->h_ext);
     if (c->ev_upload) hipEventDestroy(c->ev_upload);
     for (auto& e : c->ev) if (e) hipEventDestroy(e);
     for (auto& e : c->gemm_ev) hipEventDestroy(e);
@@ -456,6 +457,8 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     HIP_TRY(c, hipMalloc(&c->kpool.ext, sizeof(int32_t) * 2 * (size_t)std::max(1, c->max_kslots) * c->kpool.ext_blocks));
     HIP_TRY(c, hipMemset(c->kpool.ext, 0, sizeof(int32_t) * 2 * (size_t)std::max(1, c->max_kslots) * c->kpool.ext_blocks));
     if (std::getenv("CAFE_NO_KSKIP")) { (void)hipFree(c->kpool.ext); c->kpool.ext = nullptr; }    // diagnostic: every K tile of every launch
+    if (c->kpool.ext && c->N >= 256)         // (small matrices: one row tile spans most of the band anyway, and a copy per call is not free)
+        HIP_TRY(c, hipHostMalloc(&c->h_ext, sizeof(int32_t) * 2 * (size_t)std::max(1, c->max_kslots) * c->kpool.ext_blocks, hipHostMallocDefault));
     c->stats.matrix_bytes = (int64_t)(pool_bytes + kpool_bytes);
 
     // per-call parameter block (layout: cafe_ctx.h), device + pinned mirror
@@ -488,6 +491,8 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
         const char* sl = std::getenv("CAFE_GEMM_STAMPS_LAUNCH");       // diagnostics: read once, never on the call path
         c->stamps_launch = sl ? std::atol(sl) : -1;
         if (std::getenv("CAFE_USE_GRAPH")) c->use_graph = 1;
+        const char* fm = std::getenv("CAFE_FORCE_TILE");             // diagnostic, like cafe_debug_force_tile
+        if (fm && std::atoi(fm) >= 4 && std::atoi(fm) <= 9) c->force_mi = std::atoi(fm);
     }
 
     // outputs
@@ -641,6 +646,41 @@ bool rejected(const cafe_ctx* c, const cafe_params* pr, int K) {
     return (1 - 2 * alpha) < 0;
 }
 
+// Row-tile height of one K2 launch from the (previous call's) non-zero extents of its matrices: a tile runs only the K
+// tiles inside the union of its 16-row blocks' extents, so a lower tile hugs the band of a short branch more closely (at
+// config 4 the launches execute 69 % of all K tiles with 144-row tiles, 64 % with 80-row ones) but is a little less
+// efficient per MFMA and fills the persistent grid in different rounds.  Costs in units of one K tile of one 16-row block;
+// the efficiency factors are measured (forced tile heights): even heights stage a padded A tile.
+int pick_tile_height(const cafe_ctx* c, const int32_t* ext, int child, int rows, int n_col_tiles, int K) {
+    static const double eff[10] = {0, 0, 0, 0, 1.12, 1.03, 1.30, 1.06, 1.05, 1.00};
+    const int nb = c->kpool.ext_blocks, slots = 2 * c->n_cu / 8 * 8;
+    const int n_k = (c->M + 1 + kBK - 1) / kBK;
+    const double overhead = 2.0;             // prologue + epilogue of a tile, in K tiles
+    int best = 9;
+    double best_cost = 1e300;
+    for (int mi = 9; mi >= 4; --mi) {
+        if (mi == 6) continue;
+        const int row_tiles = (rows + 16 * mi - 1) / (16 * mi);
+        double work = 0;                     // sum over (category, row tile) of (K tiles + overhead) * height
+        for (int k = 0; k < K; ++k) {
+            const int32_t* e = ext + (size_t)c->slot_of[(size_t)child * c->Kmax + k] * nb * 2;
+            for (int rt = 0; rt < row_tiles; ++rt) {
+                int lo = 0x7fffffff, hi = -1;
+                for (int b = rt * mi; b < rt * mi + mi && b < nb; ++b) { lo = std::min(lo, e[2 * b]); hi = std::max(hi, e[2 * b + 1]); }
+                int nkt = n_k;
+                if (hi >= lo) nkt = std::min(hi, c->M) / kBK - lo / kBK + 1; else nkt = 1;
+                work += (nkt + overhead) * mi;
+            }
+        }
+        const double tiles = (double)row_tiles * K * n_col_tiles;
+        const double avg_tile = work / ((double)row_tiles * K);
+        const double rounds = std::ceil(tiles / slots);
+        const double cost = std::max(work * n_col_tiles / slots, rounds * avg_tile) * eff[mi];
+        if (cost < best_cost * (1.0 - 1e-9)) { best_cost = cost; best = mi; }
+    }
+    return best;
+}
+
 // The device work of one call, enqueued on `s` (or recorded into a graph being captured on `s`): parameter upload,
 // K1, the schedule (K2 / K3 launches), K4, the final sum into d_out.  Everything that changes between calls of the
 // same shape travels through the parameter block; kernel arguments depend only on (reduction, K, error model).
@@ -651,6 +691,14 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
     if (events) HIP_TRY(c, hipEventRecord(c->ev[0], s));
     HIP_TRY(c, launch_bd_matrix_build_both(c->pool, c->kpool, c->d_slots, c->d_slots + c->max_slots, c->n_slots_last, c->n_kslots_last, s));
     if (events) HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    const bool have_ext = c->h_ext && c->h_ext_valid && c->h_ext_K == K;       // the previous call's extents (same shape)
+    std::vector<int32_t> prev_ext;
+    if (have_ext) prev_ext.assign(c->h_ext, c->h_ext + (size_t)2 * c->n_kslots_last * c->kpool.ext_blocks);
+    if (c->h_ext) {                          // this call's extents for the next one; lands while the K2 launches run
+        HIP_TRY(c, hipMemcpyAsync(c->h_ext, c->kpool.ext, sizeof(int32_t) * 2 * (size_t)c->n_kslots_last * c->kpool.ext_blocks, hipMemcpyDeviceToHost, s));
+        c->h_ext_valid = true;
+        c->h_ext_K = K;
+    }
 
     // ---- prune, chunk by chunk
     c->gemm_ev_used = 0;
@@ -699,7 +747,9 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
                 g.mode = op.mode;
                 g.dst_ldt = op.to_factor ? c->factor_ld : 0;
                 g.mi = c->force_mi;                         // 0: launch_prune_gemm picks the tile height for this launch
-                g.n_row_tiles = g.mi ? (g.rows + 16 * g.mi - 1) / (16 * g.mi) : 0;
+                if (!g.mi && have_ext) g.mi = pick_tile_height(c, prev_ext.data(), op.child, g.rows, (int)(gc / kBN), K);
+                if (!g.mi) g.mi = prune_gemm_pick_mi(g.rows, (int)(gc / kBN), K, 2 * c->n_cu / 8 * 8);   // no extents yet: whole rounds x height
+                g.n_row_tiles = (g.rows + 16 * g.mi - 1) / (16 * g.mi);
                 g.n_col_tiles = (int)(gc / kBN);
                 g.stamps = (c->stamps_launch < 0 || c->stamps_launch == (long)c->stats.gemm_launches) ? c->d_stamps : nullptr;
                 g.lpool = c->pool;
@@ -719,7 +769,7 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
                 HIP_TRY(c, launch_prune_gemm(g, K, c->n_cu, s));
                 if (events && c->gemm_ev_used + 1 <= c->gemm_ev.size()) HIP_TRY(c, hipEventRecord(c->gemm_ev[c->gemm_ev_used++], s));
                 c->stats.gemm_launches += 1;
-                c->gemm_launches_info.push_back({op.child, g.rows, gc, K});
+                c->gemm_launches_info.push_back({op.child, g.rows, gc, K, g.mi});
                 c->stats.gemm_flops_dense += 2.0 * rows * (c->M + 1) * (double)gc * K;
                 c->stats.gemm_flops += 2.0 * rows * (c->M + 1) * (double)gc * K;      // (replaced by the executed count in collect_stats)
                 c->stats.gemm_flops_per_family += 2.0 * rows * (c->M + 1) * (double)cols * K;
@@ -851,7 +901,7 @@ void collect_stats(cafe_ctx* c) {
         const int n_k = (c->M + 1 + kBK - 1) / kBK;
         double executed = 0;
         for (const auto& L : c->gemm_launches_info) {
-            const int mi = c->force_mi ? c->force_mi : prune_gemm_pick_mi(L.rows, (int)(L.cols / kBN), L.K, 2 * c->n_cu / 8 * 8);
+            const int mi = L.mi;
             const int bm = 16 * mi;
             for (int k = 0; k < L.K; ++k) {
                 const int32_t* e = ext.data() + (size_t)c->slot_of[(size_t)L.child * c->Kmax + k] * nb * 2;
