@@ -75,17 +75,28 @@ __device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, cons
 #pragma unroll
     for (int i = 0; i < E; ++i) p[i] = (c0 + i == 0) ? 1.0 : 0.0;
 
+    // A lane owns E consecutive columns (what the scan needs); stored from there, an instruction would write 64 pieces of
+    // 16 bytes 8*E bytes apart.  The row is turned through LDS instead (one wave per block: a wait on the LDS counter is
+    // the only synchronisation) and leaves as 1 KB contiguous per store instruction.
+    __shared__ double2 rowbuf[64 * E / 2];
     auto store_row = [&](int r, const double* v) {
-        double* row = P + (int64_t)r * ld + j0;
 #pragma unroll
         for (int i = 0; i < E; i += 2) {
-            if (j0 + i < ld) {           // ld and j0+i are even: the pair is in or out together
-                double2 w;
-                w.x = (c0 + i < n) ? v[i] : 0.0;
-                w.y = (c0 + i + 1 < n) ? v[i + 1] : 0.0;
-                *reinterpret_cast<double2*>(row + i) = w;
-            }
+            double2 w;
+            w.x = (c0 + i < n) ? v[i] : 0.0;
+            w.y = (c0 + i + 1 < n) ? v[i + 1] : 0.0;
+            rowbuf[(j0 + i) >> 1] = w;
         }
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): every lane's part of the row is in LDS
+        __asm__ volatile("" ::: "memory");
+        double2* row = reinterpret_cast<double2*>(P + (int64_t)r * ld);
+#pragma unroll
+        for (int i = 0; i < E / 2; ++i) {
+            const int q = lane + 64 * i;                 // 16-byte piece of the row
+            if (2 * q < ld) row[q] = rowbuf[q];
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // the pieces are in registers before the next row overwrites the buffer
+        __asm__ volatile("" ::: "memory");
     };
 
     double z[E];

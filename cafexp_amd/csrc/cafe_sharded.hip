@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -131,43 +132,21 @@ int build_shard_model(const cafe_problem* p, ShardModel& m) {
     return CAFE_OK;
 }
 
-// Predicted device time (microseconds) of the shard [a, b): per interior branch one K2 launch over the node's distinct
-// columns, costed the way the launcher picks its row tile -- whole rounds of the persistent grid times the tile height
-// (prune_gemm_pick_mi; about 20 us per 16-row block of a round at two workgroups per CU, 17 us when the launch leaves the
-// CUs one workgroup each) -- plus the memory passes that write (and gather) the node's panel, about 8.4 ns per column
-// and panel touched at K = 8, M = 720 (two panels on average), plus a launch's fixed cost.  The round quantisation is the
-// point: at a 1/8 shard one column tile more can cost a whole round (8 %) on every wide launch.
+// Predicted device time of the shard [a, b), in columns: every interior branch costs one K2 launch and the memory passes
+// of the node's panel, both linear in the node's distinct columns padded to the 128-column tile, plus a launch's fixed cost
+// (about 200 columns' worth at the bench shape); the two branches under the root run over one column per family.  (Round 2
+// also tried costing a launch the way the launcher picks its row tile, whole rounds of the persistent grid x tile height:
+// before K2 skipped the all-zero K tiles that balanced eight shards better, 5 % against 7 % spread; with tiles of unequal
+// length the rounds no longer quantise a launch's time and the plain column count balances to 3.4 %.)
 double shard_cost(const ShardModel& m, int64_t a, int64_t b) {
-    const int K = m.categories, slots = 512;
-    const double panel_us_per_col = 8.4e-3 * (K / 8.0) * (m.rows_inner / 721.0);
     double cost = 0;
     for (size_t j = 0; j < m.nodes.size(); ++j) {
         const std::vector<int64_t>& pv = m.prev[j];
         int64_t cols = 0;
         for (int64_t i = a; i < b; ++i) cols += pv[i] < a;
-        const int ct = (int)(round_up64(cols, kBN) / kBN);
-        double best = 1e300;
-        int64_t best_tiles = 0;
-        for (int mi = 9; mi >= 4; --mi) {
-            const int64_t row_tiles = (m.rows_inner - 1 + 16 * mi - 1) / (16 * mi);
-            const int64_t tiles = row_tiles * ct * K;
-            const int64_t rounds = (tiles + slots - 1) / slots;
-            const double c = (double)rounds * mi * (1.0 + 0.006 * (9 - mi));
-            if (c < best * (1.0 - 1e-9)) { best = c; best_tiles = tiles; }
-        }
-        cost += best * (best_tiles <= slots / 2 ? 17.0 : 20.0) + 2.0 * panel_us_per_col * (double)(ct * kBN) + 6.0;
+        cost += (double)round_up64(cols, kBN) + 200.0;
     }
-    // the two branches under the root run over one column per (distinct) family of the shard; K4 reads that panel
-    {
-        const int ct = (int)(round_up64(b - a, kBN) / kBN);
-        double best = 1e300;
-        for (int mi = 9; mi >= 4; --mi) {
-            const int64_t tiles = (int64_t)((m.rows_root + 16 * mi - 1) / (16 * mi)) * ct * K;
-            best = std::min(best, (double)((tiles + slots - 1) / slots) * mi * (1.0 + 0.006 * (9 - mi)));
-        }
-        cost += 2.0 * best * 20.0 + 3.0 * panel_us_per_col * (double)(ct * kBN);
-    }
-    return cost;
+    return cost + 2.0 * (double)round_up64(b - a, kBN);
 }
 
 int plan_shards(const ShardModel& m, int n_shards, std::vector<int64_t>& bounds) {
@@ -212,8 +191,8 @@ int plan_shards(const ShardModel& m, int n_shards, std::vector<int64_t>& bounds)
         const double hi = eval(bounds);
         if (hi < best_hi) { best_hi = hi; best = bounds; }
     }
-    // 2. the cost is a step function of a shard's column counts (whole column tiles, whole rounds): a local search over
-    //    single cuts, steps from 1/16 of a shard down to 8 families, lowers the largest of the two neighbours
+    // 2. the cost is a step function of a shard's column counts (whole column tiles): a local search over single cuts,
+    //    steps from 1/16 of a shard down to 8 families, lowers the largest of the two neighbours
     bounds = best;
     eval(bounds);
     for (int64_t step = std::max<int64_t>(8, F / n_shards / 16); step >= 8; step /= 2) {

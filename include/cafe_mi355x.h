@@ -174,7 +174,7 @@ int cafe_comm_detach(cafe_ctx* ctx);
  * are ordered to put look-alikes next to each other (total size, then lexicographically) and cut into consecutive runs
  * of equal predicted device time.  order[n_families]: family indices in shard order; bounds[n_shards + 1]: shard r owns
  * order[bounds[r] .. bounds[r+1]).  Pure host code (no device needed); deterministic, so every rank derives the same
- * plan.  Only tree, counts, max sizes and max_categories of `problem` are read. */
+ * plan.  Only tree, counts and max sizes of `problem` are read. */
 int cafe_shard_plan(const cafe_problem* problem, int32_t n_shards, int64_t* order, int64_t* bounds);
 
 /* (2) one process, several GPUs: cafe_create_sharded plans the shards (cafe_shard_plan), creates one context per device
