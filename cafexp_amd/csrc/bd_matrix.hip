@@ -106,14 +106,30 @@ __device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, cons
     // k-major: the non-zero extent (first / last contraction index) of every block of 16 stored columns, for K2
     __shared__ int ext_lo[128], ext_hi[128];
     int first_nz = 0x7fffffff, last_nz = -1;          // over this lane's columns
-    auto note = [&](int r, const double* v) {
-        bool any = false;
+    int col_first[KMAJOR ? 1 : E], col_last[KMAJOR ? 1 : E];   // row-major: first / last row (parent size) with a non-zero entry, per owned column
 #pragma unroll
-        for (int i = 0; i < E; ++i) any = any || (c0 + i < n && v[i] != 0.0);
-        if (any) { first_nz = first_nz < r ? first_nz : r; last_nz = r; }
+    for (int i = 0; i < (KMAJOR ? 1 : E); ++i) { col_first[i] = 0x7fffffff; col_last[i] = -1; }
+    auto note = [&](int r, const double* v) {
+        if (KMAJOR) {
+            bool any = false;
+#pragma unroll
+            for (int i = 0; i < E; ++i) any = any || (c0 + i < n && v[i] != 0.0);
+            if (any) { first_nz = first_nz < r ? first_nz : r; last_nz = r; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < (KMAJOR ? 1 : E); ++i)
+                if (v[i] != 0.0) { col_first[i] = col_first[i] < r ? col_first[i] : r; col_last[i] = r; }
+        }
     };
     auto publish_extents = [&]() {
-        if (!KMAJOR || !pool.ext) return;
+        if (!pool.ext) return;
+        if (!KMAJOR) {                                 // per column x of P: rows s with P[s][x] != 0 (the support of a leaf's factor)
+            int32_t* out = pool.ext + (int64_t)slot * pool.ext_blocks * 2;
+#pragma unroll
+            for (int i = 0; i < (KMAJOR ? 1 : E); ++i)
+                if (c0 + i < n) { out[2 * (c0 + i)] = col_first[i]; out[2 * (c0 + i) + 1] = col_last[i]; }
+            return;
+        }
         const int nb = pool.ext_blocks;
         for (int b = lane; b < nb; b += 64) { ext_lo[b] = 0x7fffffff; ext_hi[b] = -1; }
         __syncthreads();                               // one wave per block: orders the LDS initialisation
@@ -127,7 +143,7 @@ __device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, cons
     };
 
     if (sp.zero) {                       // saturated / degenerate: every entry with parent size >= 1 is 0
-        if (!KMAJOR) store_row(0, p);    // row-major keeps P's row 0 = e_0; k-major never holds it
+        if (!KMAJOR) { store_row(0, p); note(0, p); }    // row-major keeps P's row 0 = e_0; k-major never holds it
         for (int r = KMAJOR ? 0 : 1; r < n_rows; ++r) store_row(r, z);
         publish_extents();               // all blocks empty
         return;
@@ -141,6 +157,7 @@ __device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, cons
         note(0, v);
     } else {
         store_row(0, p);
+        note(0, p);
     }
 
     for (int r = 1; r < n_rows; ++r) {
@@ -182,6 +199,7 @@ __device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, cons
             note(r, v);
         } else {
             store_row(r, p);
+            note(r, p);
         }
     }
     publish_extents();

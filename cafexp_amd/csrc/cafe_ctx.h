@@ -132,6 +132,15 @@ struct cafe_ctx {
     std::map<int, CallGraph> graphs;
     int use_graph = 0;
 
+    // zero extents of the likelihood panels (extents.hip): one descriptor per interior non-root node, grouped in levels of
+    // mutually independent nodes (a node's level = 1 + its deepest interior child's); per node and category the per-column
+    // and per-128-column-tile intervals outside which the panel is exactly zero
+    bool panel_extents = false;
+    cafe::ExtNode* d_ext_nodes = nullptr;
+    std::vector<int32_t*> d_colext, d_tileext;            // [n_nodes] (interior non-root nodes only)
+    struct ExtLevel { int first, count, max_col_tiles; };
+    std::vector<ExtLevel> ext_levels;
+
     // K2's row-tile height per launch is chosen from the non-zero extents of the PREVIOUS call's matrices (K1 publishes
     // them on the device; a copy lands in h_ext while the call's K2 launches run): the parameters of consecutive scorer
     // calls are close, and the choice only affects speed, never a bit of the result

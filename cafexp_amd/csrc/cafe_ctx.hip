@@ -202,8 +202,24 @@ int compute_patterns(cafe_ctx* c, const cafe_problem* p, const std::vector<int64
         const size_t U = first.size();
         std::vector<int32_t> order(U), renum(U);
         for (size_t i = 0; i < U; ++i) order[i] = (int32_t)i;
-        if (heavy >= 0)
-            std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return pid[heavy][first[x]] < pid[heavy][first[y]]; });
+        // largest leaf count under v, per pattern: the primary key (columns of similar size share a 128-column tile, whose
+        // all-zero rows K2 skips); within equal sizes the heavy child's numbering
+        std::vector<int32_t> big(U, 0);
+        {
+            std::vector<int> under;                       // taxa under v
+            std::vector<int> stack(1, v);
+            while (!stack.empty()) {
+                const int w = stack.back(); stack.pop_back();
+                if (c->leaf_taxon[w] >= 0) under.push_back(c->leaf_taxon[w]);
+                for (int u : c->children[w]) stack.push_back(u);
+            }
+            for (size_t i = 0; i < U; ++i)
+                for (int t : under) big[i] = std::max(big[i], p->counts[uniq[first[i]] * T + t]);
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+            if (big[x] != big[y]) return big[x] < big[y];
+            return heavy >= 0 && pid[heavy][first[x]] < pid[heavy][first[y]];
+        });
         rep[v].resize(U);
         for (size_t i = 0; i < U; ++i) { renum[order[i]] = (int32_t)i; rep[v][i] = first[order[i]]; }
         for (int64_t f = 0; f < F; ++f) pid[v][f] = renum[pid[v][f]];
@@ -275,7 +291,10 @@ void free_device(cafe_ctx* c) {
     comm_release(c);
     for (auto& g : c->graphs) if (g.second.exec) hipGraphExecDestroy(g.second.exec);
     c->graphs.clear();
-    hipFree(c->d_counts); hipFree(c->d_weights); hipFree(c->pool.base); hipFree(c->kpool.base); hipFree(c->kpool.ext); hipFree(c->d_params); hipFree(c->d_panels);
+    hipFree(c->d_counts); hipFree(c->d_weights); hipFree(c->pool.base); hipFree(c->kpool.base); hipFree(c->kpool.ext); hipFree(c->pool.ext); hipFree(c->d_params); hipFree(c->d_panels);
+    hipFree(c->d_ext_nodes);
+    for (auto ptr : c->d_colext) hipFree(ptr);
+    for (auto ptr : c->d_tileext) hipFree(ptr);
     hipFree(c->d_fam_out); hipFree(c->d_fam_lik); hipFree(c->d_cat_out); hipFree(c->d_failed);
     hipFree(c->d_scratch); hipFree(c->d_result); hipFree(c->d_stamps);
     for (auto ptr : c->d_edge_map) hipFree(ptr);
@@ -367,6 +386,22 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     }
     c->F_uniq = (int64_t)uniq.size();
     c->Fp = round_up64(c->F_uniq, kBN);
+    // Columns in order of the families' largest count: a likelihood column is exactly zero far from the observed sizes
+    // (node_extent_kernel), K2 skips the all-zero rows of a 128-column tile of its B operand, and a tile of families of
+    // similar size has many of them.  Internal order only: ref_of maps every family of the table to its column.
+    if (!device_counts) {
+        std::vector<int32_t> key(c->F_uniq);
+        for (int64_t u = 0; u < c->F_uniq; ++u) key[u] = *std::max_element(p->counts + uniq[u] * T, p->counts + (uniq[u] + 1) * T);
+        std::vector<int64_t> perm(c->F_uniq), inv(c->F_uniq);
+        for (int64_t u = 0; u < c->F_uniq; ++u) perm[u] = u;
+        std::stable_sort(perm.begin(), perm.end(), [&](int64_t x, int64_t y) { return key[x] < key[y]; });
+        std::vector<int64_t> nu(c->F_uniq);
+        std::vector<double> nw(c->F_uniq);
+        for (int64_t i = 0; i < c->F_uniq; ++i) { nu[i] = uniq[perm[i]]; nw[i] = c->weights[perm[i]]; inv[perm[i]] = i; }
+        uniq.swap(nu);
+        c->weights.swap(nw);
+        for (int64_t f = 0; f < c->F_all; ++f) c->ref_of[f] = inv[c->ref_of[f]];
+    }
 
     // device
     int ndev = 0;
@@ -456,10 +491,71 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     // non-zero extents of the k-major matrices (K1 writes them, K2 skips the K tiles outside them)
     HIP_TRY(c, hipMalloc(&c->kpool.ext, sizeof(int32_t) * 2 * (size_t)std::max(1, c->max_kslots) * c->kpool.ext_blocks));
     HIP_TRY(c, hipMemset(c->kpool.ext, 0, sizeof(int32_t) * 2 * (size_t)std::max(1, c->max_kslots) * c->kpool.ext_blocks));
-    if (std::getenv("CAFE_NO_KSKIP")) { (void)hipFree(c->kpool.ext); c->kpool.ext = nullptr; }    // diagnostic: every K tile of every launch
+    c->pool.ext_blocks = c->N;               // row-major: one entry per column x of a leaf branch's matrix
+    HIP_TRY(c, hipMalloc(&c->pool.ext, sizeof(int32_t) * 2 * (size_t)std::max(1, c->max_slots) * c->pool.ext_blocks));
+    HIP_TRY(c, hipMemset(c->pool.ext, 0, sizeof(int32_t) * 2 * (size_t)std::max(1, c->max_slots) * c->pool.ext_blocks));
+    if (std::getenv("CAFE_NO_KSKIP")) {      // diagnostic: every K tile of every launch
+        (void)hipFree(c->kpool.ext); c->kpool.ext = nullptr;
+        (void)hipFree(c->pool.ext); c->pool.ext = nullptr;
+    }
     if (c->kpool.ext && c->N >= 256)         // (small matrices: one row tile spans most of the band anyway, and a copy per call is not free)
         HIP_TRY(c, hipHostMalloc(&c->h_ext, sizeof(int32_t) * 2 * (size_t)std::max(1, c->max_kslots) * c->kpool.ext_blocks, hipHostMallocDefault));
     c->stats.matrix_bytes = (int64_t)(pool_bytes + kpool_bytes);
+
+    // zero extents of the panels: descriptors of the interior non-root nodes, children before parents, level by level
+    c->d_colext.assign(c->n_nodes, nullptr);
+    c->d_tileext.assign(c->n_nodes, nullptr);
+    c->panel_extents = c->subtree_dedup && c->kpool.ext && c->pool.ext && !std::getenv("CAFE_NO_PANEL_EXTENTS");
+    if (c->panel_extents) {
+        std::vector<int> level(c->n_nodes, -1);
+        int max_level = -1;
+        for (int v = 0; v < c->n_nodes && c->panel_extents; ++v) {
+            if (c->leaf_taxon[v] >= 0 || v == c->root) continue;
+            int lv = 0, n_leaf = 0, n_inner = 0;
+            for (int u : c->children[v]) {
+                if (c->leaf_taxon[u] >= 0) ++n_leaf; else { ++n_inner; lv = std::max(lv, level[u] + 1); }
+            }
+            if (n_leaf > kMaxExtChildren || n_inner > kMaxExtChildren) c->panel_extents = false;   // (a wide polytomy: no extents)
+            level[v] = lv;
+            max_level = std::max(max_level, lv);
+        }
+        if (c->panel_extents) {
+            std::vector<ExtNode> nodes;
+            for (int lv = 0; lv <= max_level; ++lv) {
+                cafe_ctx::ExtLevel L{(int)nodes.size(), 0, 0};
+                for (int v = 0; v < c->n_nodes; ++v) {
+                    if (level[v] != lv) continue;
+                    ExtNode nd{};
+                    nd.cols = (int32_t)c->pat_cols[v];
+                    HIP_TRY(c, hipMalloc(&c->d_colext[v], sizeof(int32_t) * 2 * (size_t)c->Kmax * nd.cols));
+                    HIP_TRY(c, hipMalloc(&c->d_tileext[v], sizeof(int32_t) * 2 * (size_t)c->Kmax * (nd.cols / kBN)));
+                    nd.colext = c->d_colext[v];
+                    nd.tileext = c->d_tileext[v];
+                    nd.cnt = c->d_leaf_cnt[v];
+                    nd.cnt_ld = c->pat_cols[v];
+                    for (int u : c->children[v]) {
+                        if (c->leaf_taxon[u] >= 0) {
+                            nd.leaf_pair[nd.n_leaf] = c->pair_of[u];
+                            nd.leaf_row[nd.n_leaf] = c->leaf_rank[u];
+                            ++nd.n_leaf;
+                        } else {
+                            nd.inner_pair[nd.n_inner] = c->pair_of[u];
+                            nd.inner_cols[nd.n_inner] = (int32_t)c->pat_cols[u];
+                            nd.inner_map[nd.n_inner] = c->edge_identity[u] ? nullptr : c->d_edge_map[u];
+                            nd.inner_colext[nd.n_inner] = c->d_colext[u];
+                            ++nd.n_inner;
+                        }
+                    }
+                    L.max_col_tiles = std::max(L.max_col_tiles, nd.cols / kBN);
+                    nodes.push_back(nd);
+                    ++L.count;
+                }
+                if (L.count) c->ext_levels.push_back(L);
+            }
+            HIP_TRY(c, hipMalloc(&c->d_ext_nodes, sizeof(ExtNode) * std::max<size_t>(1, nodes.size())));
+            HIP_TRY(c, hipMemcpy(c->d_ext_nodes, nodes.data(), sizeof(ExtNode) * nodes.size(), hipMemcpyHostToDevice));
+        }
+    }
 
     // per-call parameter block (layout: cafe_ctx.h), device + pinned mirror
     {
@@ -528,6 +624,7 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
         // several column chunks: the per-node column maps address whole panels, so this case keeps one column per
         // family in every panel (the schedule without combine passes needs no more panels than the one with them)
         c->subtree_dedup = false;
+        c->panel_extents = false;
         c->ops.clear();
         PanelAlloc pa;
         c->root_panel = emit_node(c, c->root, need, pa);
@@ -699,6 +796,18 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
         c->h_ext_valid = true;
         c->h_ext_K = K;
     }
+    if (c->panel_extents) {                  // zero extents of every node's panel for this call's matrices (extents.hip)
+        ExtArgs ea{};
+        ea.nodes = c->d_ext_nodes;
+        ea.leaf_ext = c->pool.ext; ea.leaf_ext_blocks = c->pool.ext_blocks; ea.n_pairs_leaf = c->n_pairs[0];
+        ea.kext = c->kpool.ext; ea.kext_blocks = c->kpool.ext_blocks; ea.n_pairs_inner = c->n_pairs[1];
+        ea.M = c->M;
+        ea.err = use_err ? c->d_err : nullptr; ea.n_dev = use_err ? c->n_dev : 0;
+        for (const auto& L : c->ext_levels) {
+            ea.first = L.first; ea.count = L.count;
+            HIP_TRY(c, launch_node_extents(ea, L.max_col_tiles, K, s));
+        }
+    }
 
     // ---- prune, chunk by chunk
     c->gemm_ev_used = 0;
@@ -760,6 +869,7 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
                 }
                 g.counts = cnt_base; g.counts_ld = cnt_ld; g.f0 = cnt_f0;
                 g.err = use_err ? c->d_err : nullptr; g.n_dev = use_err ? c->n_dev : 0; g.max_family_size = c->M;
+                g.bext = c->panel_extents ? c->d_tileext[op.child] : nullptr;
                 if (op.has_gath) {
                     g.gath_src = c->d_panels + (int64_t)op.gath_panel * c->panel_stride;
                     g.gath_ld = c->factor_ld;
@@ -900,19 +1010,30 @@ void collect_stats(cafe_ctx* c) {
         if (hipMemcpy(ext.data(), c->kpool.ext, ext.size() * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return;
         const int n_k = (c->M + 1 + kBK - 1) / kBK;
         double executed = 0;
+        std::vector<int32_t> bext;
         for (const auto& L : c->gemm_launches_info) {
             const int mi = L.mi;
             const int bm = 16 * mi;
+            const int n_ct = (int)(L.cols / kBN);
+            const bool have_b = c->panel_extents && c->d_tileext[L.child];
+            if (have_b) {
+                bext.resize((size_t)2 * L.K * n_ct);
+                if (hipMemcpy(bext.data(), c->d_tileext[L.child], bext.size() * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return;
+            }
             for (int k = 0; k < L.K; ++k) {
                 const int32_t* e = ext.data() + (size_t)c->slot_of[(size_t)L.child * c->Kmax + k] * nb * 2;
                 for (int row0 = 0; row0 < L.rows; row0 += bm) {
-                    int lo = 0x7fffffff, hi = -1;
-                    for (int b = row0 / 16; b < row0 / 16 + mi && b < nb; ++b) { lo = std::min(lo, e[2 * b]); hi = std::max(hi, e[2 * b + 1]); }
-                    if (hi < lo) { lo = 0; hi = 0; }
-                    hi = std::min(hi, c->M);
-                    const int nkt = hi / kBK - lo / kBK + 1;
-                    const int kk = std::min(nkt * kBK, c->M + 1 - (lo / kBK) * kBK);      // the last K tile of the matrix is ragged
-                    executed += 2.0 * std::min(bm, L.rows - row0) * (double)kk * (double)L.cols;
+                    int alo = 0x7fffffff, ahi = -1;
+                    for (int b = row0 / 16; b < row0 / 16 + mi && b < nb; ++b) { alo = std::min(alo, e[2 * b]); ahi = std::max(ahi, e[2 * b + 1]); }
+                    for (int ct = 0; ct < (have_b ? n_ct : 1); ++ct) {
+                        int lo = alo, hi = ahi;
+                        if (have_b) { lo = std::max(lo, bext[((size_t)k * n_ct + ct) * 2]); hi = std::min(hi, bext[((size_t)k * n_ct + ct) * 2 + 1]); }
+                        if (hi < lo) { lo = 0; hi = 0; }
+                        hi = std::min(hi, c->M);
+                        const int nkt = hi / kBK - lo / kBK + 1;
+                        const int kk = std::min(nkt * kBK, c->M + 1 - (lo / kBK) * kBK);      // the last K tile of the matrix is ragged
+                        executed += 2.0 * std::min(bm, L.rows - row0) * (double)kk * (have_b ? (double)kBN : (double)L.cols);
+                    }
                     (void)n_k;
                 }
             }

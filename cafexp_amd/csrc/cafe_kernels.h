@@ -84,6 +84,9 @@ struct GemmArgs {
     const double* gath_src;
     int64_t gath_ld;
     const int32_t* gath_map;
+    // per (category, column tile) of the CHILD panel: rows outside [bext[..][0], bext[..][1]] are exactly zero (extents.hip);
+    // nullptr: unknown
+    const int32_t* bext;
     // > 0: this launch is a factor GEMM and stores transposed, dst[column][16 - out_off + panel row], dst_ldt rows per
     // column (see prune_gemm.hip)
     int32_t dst_ldt;
@@ -115,6 +118,35 @@ struct GatherArgs {
     int64_t ld_src[2];
     const int32_t* map[2];
 };
+
+// Zero extents of the likelihood panels (extents.hip).  One ExtNode per interior non-root node, static per context.
+constexpr int kMaxExtChildren = 4;
+struct ExtNode {
+    int32_t cols;                            // padded columns of the node's panel
+    int32_t n_leaf, n_inner;
+    int32_t leaf_pair[kMaxExtChildren];      // the leaf child's branch: pair index in the row-major pool
+    int32_t leaf_row[kMaxExtChildren];       // the leaf child's row in `cnt`
+    const int32_t* cnt;                      // [leaf children][columns] observed counts
+    int64_t cnt_ld;
+    int32_t inner_pair[kMaxExtChildren];     // the interior child's branch: pair index in the k-major pool
+    int32_t inner_cols[kMaxExtChildren];
+    const int32_t* inner_map[kMaxExtChildren];      // this node's column -> the child's column (nullptr: the same)
+    const int32_t* inner_colext[kMaxExtChildren];   // the child's per-column extents [category][its columns][2]
+    int32_t* colext;                         // [category][cols][2]: rows outside [lo, hi] of a column are exactly zero
+    int32_t* tileext;                        // [category][cols / 128][2]: hull over a 128-column tile (K2's B operand)
+};
+struct ExtArgs {
+    const ExtNode* nodes;
+    int32_t first, count;                    // the nodes of one level (independent of each other)
+    const int32_t* leaf_ext;                 // row-major pool: per slot and column x, first / last row s with P[s][x] != 0
+    int32_t leaf_ext_blocks, n_pairs_leaf;
+    const int32_t* kext;                     // k-major pool: per slot and block of 16 parent sizes, first / last child size
+    int32_t kext_blocks, n_pairs_inner;
+    int32_t M;
+    const double* err;                       // error model or nullptr
+    int32_t n_dev;
+};
+hipError_t launch_node_extents(const ExtArgs& a, int max_col_tiles, int n_categories, hipStream_t stream);
 
 struct ReduceArgs {
     const double* root;             // root panel [category][i][family]
