@@ -77,6 +77,7 @@ struct ShardModel {
     std::vector<int64_t> order;                    // shard order -> family
     std::vector<int> nodes;                        // interior non-root nodes
     std::vector<std::vector<int64_t>> prev;        // [nodes.size()][F]
+    std::vector<std::vector<float>> weight;        // [nodes.size()][F] cost of the position's column at that node (see shard_cost)
     int rows_inner = 0, rows_root = 0, categories = 1;
 };
 
@@ -109,11 +110,24 @@ int build_shard_model(const cafe_problem* p, ShardModel& m) {
         seen.reserve((size_t)F * 2);
         pid[v].resize(F);
         std::vector<int64_t> pv(F);
+        std::vector<float> wt(F);
+        std::vector<int> under;                        // taxa under v
+        {
+            std::vector<int> stack(1, v);
+            while (!stack.empty()) {
+                const int w = stack.back(); stack.pop_back();
+                if (m.tree.leaf_taxon[w] >= 0) under.push_back(m.tree.leaf_taxon[w]);
+                for (int u : m.tree.children[w]) stack.push_back(u);
+            }
+        }
         std::vector<int32_t> key(kw);
         for (int64_t i = 0; i < F; ++i) {
             size_t k = 0;
             for (int u : inner) key[k++] = pid[u][i];
             for (int u : leaves) key[k++] = p->counts[m.order[i] * T + m.tree.leaf_taxon[u]];
+            int32_t big = 0;                           // largest count under v: K2 skips the all-zero rows of a column tile, and
+            for (int t : under) big = std::max(big, p->counts[m.order[i] * T + t]);   // columns of large families have few
+            wt[i] = 1.0f + 2.0f * (float)std::max(0, big - 100) / (float)std::max(1, p->max_family_size);
             std::string ks(reinterpret_cast<const char*>(key.data()), sizeof(int32_t) * kw);
             auto it = seen.find(ks);
             if (it == seen.end()) {
@@ -128,25 +142,30 @@ int build_shard_model(const cafe_problem* p, ShardModel& m) {
         }
         m.nodes.push_back(v);
         m.prev.push_back(std::move(pv));
+        m.weight.push_back(std::move(wt));
     }
     return CAFE_OK;
 }
 
 // Predicted device time of the shard [a, b), in columns: every interior branch costs one K2 launch and the memory passes
-// of the node's panel, both linear in the node's distinct columns padded to the 128-column tile, plus a launch's fixed cost
-// (about 200 columns' worth at the bench shape); the two branches under the root run over one column per family.  (Round 2
-// also tried costing a launch the way the launcher picks its row tile, whole rounds of the persistent grid x tile height:
-// before K2 skipped the all-zero K tiles that balanced eight shards better, 5 % against 7 % spread; with tiles of unequal
-// length the rounds no longer quantise a launch's time and the plain column count balances to 3.4 %.)
+// of the node's panel, both linear in the node's distinct columns, plus half a column tile of padding and a launch's fixed
+// cost (about 200 columns' worth at the bench shape); the two branches under the root run over one column per family.  A
+// column's weight is 1 up to a largest count of 100 under the node and grows by 2 per M beyond: K2 runs only the K tiles
+// inside matrix extent x panel extent, and the panels of large families have wide extents (measured on eight shards cut by
+// plain column counts: the seven with the small families 27.0-28.9 ms, the one with the largest 32.2 ms).
+// (Round 2 also tried costing a launch the way the launcher picks its row tile, whole rounds of the persistent grid x tile
+// height: before K2 skipped K tiles that balanced eight shards better than column counts; tiles of unequal length no
+// longer run in lockstep rounds.)
 double shard_cost(const ShardModel& m, int64_t a, int64_t b) {
     double cost = 0;
     for (size_t j = 0; j < m.nodes.size(); ++j) {
         const std::vector<int64_t>& pv = m.prev[j];
-        int64_t cols = 0;
-        for (int64_t i = a; i < b; ++i) cols += pv[i] < a;
-        cost += (double)round_up64(cols, kBN) + 200.0;
+        const std::vector<float>& wt = m.weight[j];
+        double cols = 0;
+        for (int64_t i = a; i < b; ++i) cols += pv[i] < a ? wt[i] : 0.0f;
+        cost += cols + 64.0 + 200.0;
     }
-    return cost + 2.0 * (double)round_up64(b - a, kBN);
+    return cost + 2.0 * (double)(b - a);
 }
 
 int plan_shards(const ShardModel& m, int n_shards, std::vector<int64_t>& bounds) {
