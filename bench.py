@@ -304,6 +304,8 @@ def main():
         ms_mat += st["ms_matrices"]; ms_prune += st["ms_prune"]
     fence()
     elapsed = time.perf_counter() - t0
+    # what the K2 launches of a step really executed (the same every step: same parameters); counted once, outside the timing
+    flops_executed = ctx.executed_flops() * args.steps
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if native_comm else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -312,7 +314,7 @@ def main():
     rc = 0
     if rank == 0:
         st = ctx.stats()
-        achieved = flops / (ms_gemm * 1e-3) / 1e12 if ms_gemm > 0 else 0.0
+        achieved = flops_executed / (ms_gemm * 1e-3) / 1e12 if ms_gemm > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):                     # PMC passes of this same workload (profiles/)
@@ -337,11 +339,11 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": "prune_gemm_kernel", "launches_per_step": launches // max(1, args.steps),
-                         "avg_launch_ms": ms_gemm / max(1, launches), "flops_per_launch": flops / max(1, launches),
+                         "avg_launch_ms": ms_gemm / max(1, launches), "flops_per_launch": flops_executed / max(1, launches),
                          # flops_per_launch = what the launches EXECUTE: columns = distinct subtree patterns, K tiles = those
                          # inside a row tile's non-zero extent (DESIGN.md sections 2, 3).  With every K tile of those
                          # columns, and with one column per family at every node (SURVEY 8d's per-family figure):
-                         "flops_per_launch_all_k_tiles": flops_dense / max(1, launches),
+                         "flops_per_launch_all_k_tiles": flops / max(1, launches),
                          "flops_per_launch_one_column_per_family": flops_fam / max(1, launches)},
             "phases_ms_per_step": {"bd_matrix_build": ms_mat / args.steps, "prune_total": ms_prune / args.steps,
                                    "prune_gemm": ms_gemm / args.steps},
@@ -366,7 +368,7 @@ def main():
                 sec, v = timed_calls(lambda: plain.score(pr, alpha=args.alpha), 2)
                 ps = plain.stats()
                 out["one_column_per_family"] = {"ms_per_step": 1e3 * sec, "value": F / sec, "neg_lnl": v,
-                                                "prune_gemm_tflops": ps["gemm_flops"] / (ps["ms_gemm"] * 1e-3) / 1e12 if ps["ms_gemm"] > 0 else None,
+                                                "prune_gemm_tflops": plain.executed_flops() / (ps["ms_gemm"] * 1e-3) / 1e12 if ps["ms_gemm"] > 0 else None,
                                                 "identical_to_headline": v == value}
                 plain.close()
                 out["other_configs"] = other_configs(args)

@@ -69,7 +69,7 @@ EXPORTS = [
     "cafe_root_max", "cafe_reconstruct", "cafe_branch_probabilities", "cafe_pvalues", "cafe_debug_force_tile",
     "cafe_comm_unique_id", "cafe_comm_attach", "cafe_comm_detach", "cafe_shard_plan", "cafe_create_sharded",
     "cafe_sharded_destroy", "cafe_sharded_last_error", "cafe_sharded_score", "cafe_sharded_family_results",
-    "cafe_sharded_size", "cafe_sharded_context", "cafe_set_graphs",
+    "cafe_sharded_size", "cafe_sharded_context", "cafe_set_graphs", "cafe_executed_flops",
 ]
 CAFE_COMM_ID_BYTES = 128
 
@@ -139,6 +139,8 @@ def load():
     L.cafe_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.cafe_set_graphs.restype = C.c_int
     L.cafe_set_graphs.argtypes = [C.c_void_p, C.c_int]
+    L.cafe_executed_flops.restype = C.c_int
+    L.cafe_executed_flops.argtypes = [C.c_void_p, _f64p]
     L.cafe_comm_unique_id.restype = C.c_int
     L.cafe_comm_unique_id.argtypes = [C.c_char_p]
     L.cafe_comm_attach.restype = C.c_int
@@ -389,6 +391,12 @@ class Context:
         st = CafeStats()
         self._check(self._lib.cafe_get_stats(self._h, C.byref(st)))
         return st.as_dict()
+
+    def executed_flops(self) -> float:
+        """Flops the K2 launches of the last call really ran (K tiles outside matrix extent x panel extent are skipped)."""
+        v = C.c_double()
+        self._check(self._lib.cafe_executed_flops(self._h, C.byref(v)))
+        return v.value
 
     def debug_stamps(self, words: int) -> np.ndarray:
         out = np.zeros(words, dtype=np.uint64)

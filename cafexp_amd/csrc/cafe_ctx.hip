@@ -881,7 +881,7 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
                 c->stats.gemm_launches += 1;
                 c->gemm_launches_info.push_back({op.child, g.rows, gc, K, g.mi});
                 c->stats.gemm_flops_dense += 2.0 * rows * (c->M + 1) * (double)gc * K;
-                c->stats.gemm_flops += 2.0 * rows * (c->M + 1) * (double)gc * K;      // (replaced by the executed count in collect_stats)
+                c->stats.gemm_flops += 2.0 * rows * (c->M + 1) * (double)gc * K;      // (cafe_executed_flops counts what the tiles really ran)
                 c->stats.gemm_flops_per_family += 2.0 * rows * (c->M + 1) * (double)cols * K;
                 c->stats.gemm_bytes += 8.0 * K * ((double)rows * (c->M + 1) + (double)(c->M + 1) * gc + (double)rows * gc);
             }
@@ -900,7 +900,7 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
     // (the pair also goes straight into pinned host memory: cafe_score without a communicator reads it there after the
     // stream has drained, no device-to-host copy)
     HIP_TRY(c, launch_final_sum(c->d_fam_out, c->d_weights, c->d_failed, c->F_uniq, c->d_scratch, c->n_scratch, d_out, c->h_result, s));
-    if (events) { HIP_TRY(c, hipEventRecord(c->ev[3], s)); c->events_valid = true; c->stats_flops_stale = true; }
+    if (events) { HIP_TRY(c, hipEventRecord(c->ev[3], s)); c->events_valid = true; }
     return CAFE_OK;
 }
 
@@ -992,22 +992,18 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bo
     return CAFE_OK;
 }
 
-void collect_stats(cafe_ctx* c) {
-    if (!c->events_valid) return;
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->stats.ms_matrices = ms;
-    if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->stats.ms_prune = ms;
-    if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->stats.ms_reduce = ms;
-    double g = 0;
-    for (size_t i = 0; i + 1 < c->gemm_ev_used; i += 2)
-        if (hipEventElapsedTime(&ms, c->gemm_ev[i], c->gemm_ev[i + 1]) == hipSuccess) g += ms;
-    c->stats.ms_gemm = g;
+
+// Flops the K2 launches of the last (profiled) call EXECUTED: a (row tile, column tile) pair runs only the K tiles inside
+// matrix extent x panel extent, so read the extents this call published and count, per launch, what its tiles ran.  Reads
+// the extents back (a few synchronous copies, milliseconds of host work): for measurement, once, not per call.
+double count_executed_flops(cafe_ctx* c) {
+    if (!c->kpool.ext || c->gemm_launches_info.empty()) return c->stats.gemm_flops;
     // flops the K2 launches EXECUTED: K tiles outside a row tile's non-zero extent are skipped, so read the extents K1
     // published for this call and count, per launch, what its row tiles ran (same tile height as the launcher picks)
-    if (c->kpool.ext && !c->gemm_launches_info.empty() && c->stats_flops_stale) {
+    {
         const int nb = c->kpool.ext_blocks;
         std::vector<int32_t> ext((size_t)2 * c->max_kslots * nb);
-        if (hipMemcpy(ext.data(), c->kpool.ext, ext.size() * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return;
+        if (hipMemcpy(ext.data(), c->kpool.ext, ext.size() * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
         const int n_k = (c->M + 1 + kBK - 1) / kBK;
         double executed = 0;
         std::vector<int32_t> bext;
@@ -1018,7 +1014,7 @@ void collect_stats(cafe_ctx* c) {
             const bool have_b = c->panel_extents && c->d_tileext[L.child];
             if (have_b) {
                 bext.resize((size_t)2 * L.K * n_ct);
-                if (hipMemcpy(bext.data(), c->d_tileext[L.child], bext.size() * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return;
+                if (hipMemcpy(bext.data(), c->d_tileext[L.child], bext.size() * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
             }
             for (int k = 0; k < L.K; ++k) {
                 const int32_t* e = ext.data() + (size_t)c->slot_of[(size_t)L.child * c->Kmax + k] * nb * 2;
@@ -1038,10 +1034,22 @@ void collect_stats(cafe_ctx* c) {
                 }
             }
         }
-        c->stats.gemm_flops = executed;
-        c->stats_flops_stale = false;
+        return executed;
     }
 }
+
+void collect_stats(cafe_ctx* c) {
+    if (!c->events_valid) return;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->stats.ms_matrices = ms;
+    if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->stats.ms_prune = ms;
+    if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->stats.ms_reduce = ms;
+    double g = 0;
+    for (size_t i = 0; i + 1 < c->gemm_ev_used; i += 2)
+        if (hipEventElapsedTime(&ms, c->gemm_ev[i], c->gemm_ev[i + 1]) == hipSuccess) g += ms;
+    c->stats.ms_gemm = g;
+}
+
 
 }  // namespace
 
@@ -1260,6 +1268,18 @@ int cafe_debug_force_tile(cafe_ctx* ctx, int mi) {
 int cafe_set_profiling(cafe_ctx* ctx, int on) {
     if (!ctx) return CAFE_ERR_ARGUMENT;
     ctx->profile = on ? 1 : 0;
+    return CAFE_OK;
+}
+
+int cafe_executed_flops(cafe_ctx* ctx, double* flops) {
+    if (!ctx || !flops) return CAFE_ERR_ARGUMENT;
+    if (!ctx->have_results) { set_err(ctx, "cafe_executed_flops: no completed call"); return CAFE_ERR_STATE; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+    if (ctx->gemm_launches_info.empty()) { set_err(ctx, "cafe_executed_flops: the last call was not enqueued launch by launch (a graph replay keeps no launch list)"); return CAFE_ERR_STATE; }
+    const double v = count_executed_flops(ctx);
+    if (v < 0) { set_err(ctx, "cafe_executed_flops: reading the extents back failed"); return CAFE_ERR_DEVICE; }
+    *flops = v;
     return CAFE_OK;
 }
 

@@ -115,10 +115,9 @@ typedef struct cafe_stats {
     double ms_prune;                 /* K2 prune_gemm + K3 leaf_gather over all nodes */
     double ms_gemm;                  /* K2 only */
     double ms_reduce;                /* K4 root_reduce */
-    double gemm_flops;               /* flops the K2 launches executed (profiling on): per row tile 2*rows*k*columns over the
-                                        K tiles inside the tile's non-zero extent (entries far from a short branch's
-                                        diagonal underflow to exact zeros; those K tiles are skipped), columns = the
-                                        distinct subtree patterns the launch processes */
+    double gemm_flops;               /* sum over launches of 2*rows*(M+1)*columns, columns = the distinct subtree patterns the
+                                        launch processes: every K tile of those columns.  What the tiles really ran (K2
+                                        skips the K tiles outside matrix extent x panel extent): cafe_executed_flops */
     double gemm_bytes;               /* algorithmic bytes of the same launches (P + B read, C written) */
     double gemm_flops_per_family;    /* the same sum with one column per (distinct) family at every node: SURVEY 8d's
                                         per-family figure, what the launches would compute without the sharing */
@@ -132,7 +131,7 @@ typedef struct cafe_stats {
     int64_t n_assemble_passes;       /* K3 launches that spread factor panels of de-duplicated children over a parent's columns */
     int64_t n_gather_epilogues;      /* K2 launches that fold a sibling's factor panel into their epilogue instead */
     int64_t n_leaf_passes;           /* K3 launches with leaf children only (cherries, polytomies, error models) */
-    double gemm_flops_dense;         /* the same launches with every K tile: sum of 2*rows*(M+1)*columns */
+    double gemm_flops_dense;         /* = gemm_flops */
 } cafe_stats;
 
 /* NULL on failure; err (optional, errlen bytes) receives the reason. */
@@ -230,6 +229,11 @@ int cafe_branch_probabilities(cafe_ctx* ctx, const cafe_params* params, const in
 int cafe_get_matrix(cafe_ctx* ctx, int32_t node, int32_t category, double* out, size_t out_len);
 int cafe_get_root_likelihoods(cafe_ctx* ctx, int64_t family, int32_t category, double* out, size_t out_len);
 int cafe_get_stats(const cafe_ctx* ctx, cafe_stats* stats);
+/* Flops the K2 launches of the last call executed: a (row tile, column tile) pair runs only the K tiles inside the
+ * intersection of the matrix's non-zero extent (K1) and the panel's (extents.hip) -- the products it leaves out all have an
+ * exact zero in them.  Reads the extents back and counts on the host (milliseconds): measurement only.  Needs a call that
+ * was enqueued launch by launch (no graph replay). */
+int cafe_executed_flops(cafe_ctx* ctx, double* flops);
 int cafe_matrix_size(const cafe_ctx* ctx);
 /* 1: bracket the phases and every K2 launch with HIP events so that cafe_stats.ms_* are measured (bench.py does).
  * 0 (default): no events. */
