@@ -69,7 +69,7 @@ EXPORTS = [
     "cafe_root_max", "cafe_reconstruct", "cafe_branch_probabilities", "cafe_pvalues", "cafe_debug_force_tile",
     "cafe_comm_unique_id", "cafe_comm_attach", "cafe_comm_detach", "cafe_shard_plan", "cafe_create_sharded",
     "cafe_sharded_destroy", "cafe_sharded_last_error", "cafe_sharded_score", "cafe_sharded_family_results",
-    "cafe_sharded_size", "cafe_sharded_context", "cafe_set_graphs", "cafe_executed_flops",
+    "cafe_sharded_size", "cafe_sharded_context", "cafe_set_graphs", "cafe_executed_flops", "cafe_get_extents",
 ]
 CAFE_COMM_ID_BYTES = 128
 
@@ -139,6 +139,8 @@ def load():
     L.cafe_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.cafe_set_graphs.restype = C.c_int
     L.cafe_set_graphs.argtypes = [C.c_void_p, C.c_int]
+    L.cafe_get_extents.restype = C.c_int
+    L.cafe_get_extents.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _i32p, C.c_size_t, _i32p, C.c_size_t, _i32p]
     L.cafe_executed_flops.restype = C.c_int
     L.cafe_executed_flops.argtypes = [C.c_void_p, _f64p]
     L.cafe_comm_unique_id.restype = C.c_int
@@ -391,6 +393,16 @@ class Context:
         st = CafeStats()
         self._check(self._lib.cafe_get_stats(self._h, C.byref(st)))
         return st.as_dict()
+
+    def extents(self, node: int, category: int = 0):
+        """(matrix extents [blocks or N][2], panel tile extents [tiles][2] or None) of the last call (cafe_get_extents)."""
+        n = self._lib.cafe_matrix_size(self._h)
+        m = np.zeros((max(n, (n + 14) // 16), 2), dtype=np.int32)
+        pt = np.zeros((self.n_families // 128 + 2, 2), dtype=np.int32)
+        nt = C.c_int32()
+        self._check(self._lib.cafe_get_extents(self._h, node, category, _p(m, _i32p), m.size, _p(pt, _i32p), pt.size, C.byref(nt)))
+        leaf = self.problem.leaf_taxon[node] >= 0
+        return (m[:n] if leaf else m[:(n - 1 + 15) // 16]), (pt[:nt.value] if nt.value else None)
 
     def executed_flops(self) -> float:
         """Flops the K2 launches of the last call really ran (K tiles outside matrix extent x panel extent are skipped)."""

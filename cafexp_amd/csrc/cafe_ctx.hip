@@ -204,7 +204,7 @@ int compute_patterns(cafe_ctx* c, const cafe_problem* p, const std::vector<int64
         for (size_t i = 0; i < U; ++i) order[i] = (int32_t)i;
         // largest leaf count under v, per pattern: the primary key (columns of similar size share a 128-column tile, whose
         // all-zero rows K2 skips); within equal sizes the heavy child's numbering
-        std::vector<int32_t> big(U, 0);
+        std::vector<int32_t> big(U, 0), small(U, 0x7fffffff);
         {
             std::vector<int> under;                       // taxa under v
             std::vector<int> stack(1, v);
@@ -214,10 +214,16 @@ int compute_patterns(cafe_ctx* c, const cafe_problem* p, const std::vector<int64
                 for (int u : c->children[w]) stack.push_back(u);
             }
             for (size_t i = 0; i < U; ++i)
-                for (int t : under) big[i] = std::max(big[i], p->counts[uniq[first[i]] * T + t]);
+                for (int t : under) {
+                    const int32_t x = p->counts[uniq[first[i]] * T + t];
+                    big[i] = std::max(big[i], x);
+                    small[i] = std::min(small[i], x);
+                }
         }
+        // (the lower end of a column's non-zero rows follows its largest count, the upper end its smallest)
         std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
             if (big[x] != big[y]) return big[x] < big[y];
+            if (small[x] != small[y]) return small[x] < small[y];
             return heavy >= 0 && pid[heavy][first[x]] < pid[heavy][first[y]];
         });
         rep[v].resize(U);
@@ -1268,6 +1274,34 @@ int cafe_debug_force_tile(cafe_ctx* ctx, int mi) {
 int cafe_set_profiling(cafe_ctx* ctx, int on) {
     if (!ctx) return CAFE_ERR_ARGUMENT;
     ctx->profile = on ? 1 : 0;
+    return CAFE_OK;
+}
+
+int cafe_get_extents(cafe_ctx* ctx, int32_t node, int32_t category, int32_t* matrix_ext, size_t matrix_ext_len,
+                     int32_t* panel_ext, size_t panel_ext_len, int32_t* n_tiles) {
+    if (!ctx) return CAFE_ERR_ARGUMENT;
+    if (!ctx->have_results || ctx->last_rejected) { set_err(ctx, "cafe_get_extents: no completed call"); return CAFE_ERR_STATE; }
+    if (node < 0 || node >= ctx->n_nodes || node == ctx->root || category < 0 || category >= ctx->K_last) {
+        set_err(ctx, "cafe_get_extents: node/category out of range");
+        return CAFE_ERR_ARGUMENT;
+    }
+    if (!ctx->kpool.ext || !ctx->pool.ext) { set_err(ctx, "cafe_get_extents: extents are switched off"); return CAFE_ERR_STATE; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+    const bool leaf = ctx->leaf_taxon[node] >= 0;
+    const MatrixPool& mp = leaf ? ctx->pool : ctx->kpool;
+    const int slot = ctx->slot_of[(size_t)node * ctx->Kmax + category];
+    if (matrix_ext) {
+        if (matrix_ext_len < (size_t)2 * mp.ext_blocks) { set_err(ctx, "cafe_get_extents: matrix_ext too small"); return CAFE_ERR_ARGUMENT; }
+        HIP_TRY(ctx, hipMemcpy(matrix_ext, mp.ext + (size_t)slot * mp.ext_blocks * 2, sizeof(int32_t) * 2 * mp.ext_blocks, hipMemcpyDeviceToHost));
+    }
+    if (n_tiles) *n_tiles = 0;
+    if (panel_ext && !leaf && ctx->panel_extents && ctx->d_tileext[node]) {
+        const int nt = (int)(ctx->pat_cols[node] / kBN);
+        if (panel_ext_len < (size_t)2 * nt) { set_err(ctx, "cafe_get_extents: panel_ext too small"); return CAFE_ERR_ARGUMENT; }
+        HIP_TRY(ctx, hipMemcpy(panel_ext, ctx->d_tileext[node] + (size_t)category * nt * 2, sizeof(int32_t) * 2 * nt, hipMemcpyDeviceToHost));
+        if (n_tiles) *n_tiles = nt;
+    }
     return CAFE_OK;
 }
 

@@ -228,6 +228,14 @@ int cafe_branch_probabilities(cafe_ctx* ctx, const cafe_params* params, const in
  * likelihood vector (R values: inference_prune's return) of family f in category k. */
 int cafe_get_matrix(cafe_ctx* ctx, int32_t node, int32_t category, double* out, size_t out_len);
 int cafe_get_root_likelihoods(cafe_ctx* ctx, int64_t family, int32_t category, double* out, size_t out_len);
+/* The zero extents the last call worked with (parity tests: they must contain every non-zero).
+ *   matrix_ext: the branch above `node` in `category` -- an interior branch: per block of 16 parent sizes s = 16b+1..16b+16
+ *               the first / last child size with a non-zero entry, [ceil((N-1)/16)][2]; a leaf branch: per child size
+ *               (column) x the first / last parent size with P[s][x] != 0, [N][2].  first > last: all zero.
+ *   panel_ext:  interior non-root nodes, or NULL: per 128-column tile of the node's panel the first / last row (size) that
+ *               may be non-zero, [columns / 128][2]; *n_tiles receives the number of tiles. */
+int cafe_get_extents(cafe_ctx* ctx, int32_t node, int32_t category, int32_t* matrix_ext, size_t matrix_ext_len,
+                     int32_t* panel_ext, size_t panel_ext_len, int32_t* n_tiles);
 int cafe_get_stats(const cafe_ctx* ctx, cafe_stats* stats);
 /* Flops the K2 launches of the last call executed: a (row tile, column tile) pair runs only the K tiles inside the
  * intersection of the matrix's non-zero extent (K1) and the panel's (extents.hip) -- the products it leaves out all have an

@@ -586,3 +586,53 @@ def test_only_the_needed_matrices_are_built_documented_difference(capi, oracle):
         got = ctx.matrix(v)
         cols = n if pb.leaf_taxon[v] >= 0 else 21
         assert np.abs(got[:, :cols] - want[:, :cols]).max() <= VEC_TOL
+
+
+def test_zero_extents_contain_every_nonzero_and_change_no_bit(capi, oracle, monkeypatch):
+    """K1 publishes, per matrix, where its entries are not exactly zero (per block of 16 parent sizes of an interior
+    branch, per column of a leaf branch); extents.hip propagates per-column intervals up the tree; K2 runs only the K tiles
+    inside matrix extent x panel extent.  (1) Every non-zero entry of every matrix lies inside the published extents.
+    (2) With the skipping switched off (CAFE_NO_KSKIP) every per-family value has the same bits.  (3) The launches executed
+    fewer flops than all their K tiles."""
+    pb, _ = synth.make_problem(n_taxa=16, n_families=1500, max_count=250, lam_sim=0.003, seed=11, root_cap=120)
+    probs, mult = oracle.discrete_gamma(3, 1.1)
+    pr = P.Params(lambdas=np.array([0.0015]), prior=P.prior_uniform(pb.max_root_family_size), multipliers=mult, cat_probs=probs)
+    ctx = capi.Context(pb, max_categories=3)
+    ctx.set_profiling(True)                                  # (a launch list for executed_flops)
+    v1, r1 = ctx.score(pr, alpha=1.1, per_family=True)
+    M, n = pb.max_family_size, pb.matrix_size
+    some_zero = False
+    for node in range(pb.n_nodes):
+        if pb.parent[node] < 0:
+            continue
+        for k in (0, 2):
+            Pm = ctx.matrix(node, k)
+            ext, tiles = ctx.extents(node, k)
+            if pb.leaf_taxon[node] >= 0:                     # per column x: rows s with P[s][x] != 0
+                for x in range(0, n, 7):
+                    rows = np.nonzero(Pm[:, x])[0]
+                    if len(rows):
+                        assert ext[x, 0] <= rows[0] and rows[-1] <= ext[x, 1], (node, k, x)
+                    some_zero = some_zero or len(rows) < n
+            else:                                            # per block of 16 parent sizes 16b+1..16b+16: child sizes 0..M
+                for b in range(len(ext)):
+                    blk = Pm[16 * b + 1:16 * b + 17, :M + 1]
+                    cols = np.nonzero((blk != 0).any(axis=0))[0]
+                    if len(cols):
+                        assert ext[b, 0] <= cols[0] and cols[-1] <= ext[b, 1], (node, k, b)
+                assert tiles is not None and np.all(tiles[:, 1] <= M)
+    assert some_zero                                         # the case does have exact zeros to skip
+    st = ctx.stats()
+    assert 0 < ctx.executed_flops() < st["gemm_flops"]
+    monkeypatch.setenv("CAFE_NO_KSKIP", "1")
+    full = capi.Context(pb, max_categories=3)
+    full.set_profiling(True)
+    v2, r2 = full.score(pr, alpha=1.1, per_family=True)
+    assert full.executed_flops() == full.stats()["gemm_flops"]
+    assert v1 == v2
+    for key in r1:
+        assert np.array_equal(r1[key], r2[key]), key
+    sel = np.arange(0, pb.n_families, 53)
+    sub = dataclasses.replace(pb, counts=pb.counts[sel].copy(), family_ids=[pb.family_ids[i] for i in sel])
+    _, cat, fam = oracle.score_gamma(sub, pr, per_family=True)
+    assert np.max(np.abs(r1["family_likelihood"][sel] / fam - 1)) <= 1e-11
