@@ -248,11 +248,13 @@ int compute_patterns(cafe_ctx* c, const cafe_problem* p, const std::vector<int64
         const double Uv = (double)rep[space[v]].size();
         double extra = 0;
         for (int u : inner) extra += 1.0 - (double)rep[u].size() / Uv;
-        const bool inherit = !inner.empty() && n_leaves <= 1 && extra < 0.15;
+        static const double thr_all = std::getenv("CAFE_INHERIT_ALL") ? std::atof(std::getenv("CAFE_INHERIT_ALL")) : 0.15;
+        static const double thr_big = std::getenv("CAFE_INHERIT_BIG") ? std::atof(std::getenv("CAFE_INHERIT_BIG")) : 0.12;
+        const bool inherit = !inner.empty() && n_leaves <= 1 && extra < thr_all;
         for (int u : inner) space[u] = inherit ? space[v] : u;
         if (!inherit && inner.size() == 2 && n_leaves == 0) {
             const int big = rep[inner[0]].size() >= rep[inner[1]].size() ? inner[0] : inner[1];
-            if (1.0 - (double)rep[big].size() / Uv < 0.12) space[big] = space[v];
+            if (1.0 - (double)rep[big].size() / Uv < thr_big) space[big] = space[v];
         }
     }
     // ---- 3. tables
