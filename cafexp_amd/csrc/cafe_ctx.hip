@@ -502,7 +502,10 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     c->pool.ext_blocks = c->N;               // row-major: one entry per column x of a leaf branch's matrix
     HIP_TRY(c, hipMalloc(&c->pool.ext, sizeof(int32_t) * 2 * (size_t)std::max(1, c->max_slots) * c->pool.ext_blocks));
     HIP_TRY(c, hipMemset(c->pool.ext, 0, sizeof(int32_t) * 2 * (size_t)std::max(1, c->max_slots) * c->pool.ext_blocks));
-    if (std::getenv("CAFE_NO_KSKIP")) {      // diagnostic: every K tile of every launch
+    // diagnostic CAFE_NO_KSKIP: every K tile of every launch.  Small matrices (mammals: N = 141, 9 K tiles): a row tile spans
+    // most of the band anyway, and the extent kernels and lookups cost more than the few K tiles they would save (measured:
+    // 0.34 -> 0.38 ms per call with them) -- no extents below N = 256 unless CAFE_FORCE_KSKIP asks for them
+    if (std::getenv("CAFE_NO_KSKIP") || (c->N < 256 && !std::getenv("CAFE_FORCE_KSKIP"))) {
         (void)hipFree(c->kpool.ext); c->kpool.ext = nullptr;
         (void)hipFree(c->pool.ext); c->pool.ext = nullptr;
     }

@@ -595,6 +595,7 @@ def test_zero_extents_contain_every_nonzero_and_change_no_bit(capi, oracle, monk
     (2) With the skipping switched off (CAFE_NO_KSKIP) every per-family value has the same bits.  (3) The launches executed
     fewer flops than all their K tiles."""
     pb, _ = synth.make_problem(n_taxa=16, n_families=1500, max_count=250, lam_sim=0.003, seed=11, root_cap=120)
+    assert pb.matrix_size >= 256                             # (below that the library does not bother with extents)
     probs, mult = oracle.discrete_gamma(3, 1.1)
     pr = P.Params(lambdas=np.array([0.0015]), prior=P.prior_uniform(pb.max_root_family_size), multipliers=mult, cat_probs=probs)
     ctx = capi.Context(pb, max_categories=3)

@@ -61,7 +61,7 @@ def main():
         w_b = 1024.0 * sum(write[g]) / len(write[g])
         doc = {
             "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over "
-                      "`python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline`; tools/summarize_profiles.py",
+                      "`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras`; tools/summarize_profiles.py",
             "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of a 16 B/lane coalesced stream "
                           "(MI355X_MICROARCH.md, HBM) -> doubled; WRITE_SIZE exact; unit KB",
             "raw": {"FETCH_SIZE_KB": per_launch(fetch), "WRITE_SIZE_KB": per_launch(write)},
@@ -77,7 +77,7 @@ def main():
             json.dump(doc, fh, indent=1)
     elif mode == "sq":
         c = counters(sys.argv[2])
-        doc = {"source": "rocprofv3 --pmc <SQ counters> over `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline`",
+        doc = {"source": "rocprofv3 --pmc <SQ counters> over `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras`",
                "per_launch": {name: per_launch(v) for name, v in c.items()}}
         with open(sys.argv[3], "w") as fh:
             json.dump(doc, fh, indent=1)
