@@ -513,61 +513,6 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
         HIP_TRY(c, hipHostMalloc(&c->h_ext, sizeof(int32_t) * 2 * (size_t)std::max(1, c->max_kslots) * c->kpool.ext_blocks, hipHostMallocDefault));
     c->stats.matrix_bytes = (int64_t)(pool_bytes + kpool_bytes);
 
-    // zero extents of the panels: descriptors of the interior non-root nodes, children before parents, level by level
-    c->d_colext.assign(c->n_nodes, nullptr);
-    c->d_tileext.assign(c->n_nodes, nullptr);
-    c->panel_extents = c->subtree_dedup && c->kpool.ext && c->pool.ext && !std::getenv("CAFE_NO_PANEL_EXTENTS");
-    if (c->panel_extents) {
-        std::vector<int> level(c->n_nodes, -1);
-        int max_level = -1;
-        for (int v = 0; v < c->n_nodes && c->panel_extents; ++v) {
-            if (c->leaf_taxon[v] >= 0 || v == c->root) continue;
-            int lv = 0, n_leaf = 0, n_inner = 0;
-            for (int u : c->children[v]) {
-                if (c->leaf_taxon[u] >= 0) ++n_leaf; else { ++n_inner; lv = std::max(lv, level[u] + 1); }
-            }
-            if (n_leaf > kMaxExtChildren || n_inner > kMaxExtChildren) c->panel_extents = false;   // (a wide polytomy: no extents)
-            level[v] = lv;
-            max_level = std::max(max_level, lv);
-        }
-        if (c->panel_extents) {
-            std::vector<ExtNode> nodes;
-            for (int lv = 0; lv <= max_level; ++lv) {
-                cafe_ctx::ExtLevel L{(int)nodes.size(), 0, 0};
-                for (int v = 0; v < c->n_nodes; ++v) {
-                    if (level[v] != lv) continue;
-                    ExtNode nd{};
-                    nd.cols = (int32_t)c->pat_cols[v];
-                    HIP_TRY(c, hipMalloc(&c->d_colext[v], sizeof(int32_t) * 2 * (size_t)c->Kmax * nd.cols));
-                    HIP_TRY(c, hipMalloc(&c->d_tileext[v], sizeof(int32_t) * 2 * (size_t)c->Kmax * (nd.cols / kBN)));
-                    nd.colext = c->d_colext[v];
-                    nd.tileext = c->d_tileext[v];
-                    nd.cnt = c->d_leaf_cnt[v];
-                    nd.cnt_ld = c->pat_cols[v];
-                    for (int u : c->children[v]) {
-                        if (c->leaf_taxon[u] >= 0) {
-                            nd.leaf_pair[nd.n_leaf] = c->pair_of[u];
-                            nd.leaf_row[nd.n_leaf] = c->leaf_rank[u];
-                            ++nd.n_leaf;
-                        } else {
-                            nd.inner_pair[nd.n_inner] = c->pair_of[u];
-                            nd.inner_cols[nd.n_inner] = (int32_t)c->pat_cols[u];
-                            nd.inner_map[nd.n_inner] = c->edge_identity[u] ? nullptr : c->d_edge_map[u];
-                            nd.inner_colext[nd.n_inner] = c->d_colext[u];
-                            ++nd.n_inner;
-                        }
-                    }
-                    L.max_col_tiles = std::max(L.max_col_tiles, nd.cols / kBN);
-                    nodes.push_back(nd);
-                    ++L.count;
-                }
-                if (L.count) c->ext_levels.push_back(L);
-            }
-            HIP_TRY(c, hipMalloc(&c->d_ext_nodes, sizeof(ExtNode) * std::max<size_t>(1, nodes.size())));
-            HIP_TRY(c, hipMemcpy(c->d_ext_nodes, nodes.data(), sizeof(ExtNode) * nodes.size(), hipMemcpyHostToDevice));
-        }
-    }
-
     // per-call parameter block (layout: cafe_ctx.h), device + pinned mirror
     {
         size_t off = sizeof(SlotParam) * (size_t)(c->max_slots + c->max_kslots);
@@ -654,6 +599,64 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     c->stats.panel_bytes = (int64_t)panel_bytes;
     c->stats.n_unique_families = c->F_uniq;
     c->stats.n_chunks = (c->Fp + c->chunk_cols - 1) / c->chunk_cols;
+
+    // zero extents of the panels: descriptors of the interior non-root nodes, children before parents, level by level
+    c->d_colext.assign(c->n_nodes, nullptr);
+    c->d_tileext.assign(c->n_nodes, nullptr);
+    // (one column per family at every node -- CAFE_FLAG_NO_SUBTREE_DEDUP, device-written counts -- works the same way as long
+    // as the families fit one column chunk: every edge is the identity and the counts are the family table itself)
+    c->panel_extents = (c->subtree_dedup || c->stats.n_chunks == 1) && c->kpool.ext && c->pool.ext && !std::getenv("CAFE_NO_PANEL_EXTENTS");
+    if (c->panel_extents) {
+        std::vector<int> level(c->n_nodes, -1);
+        int max_level = -1;
+        for (int v = 0; v < c->n_nodes && c->panel_extents; ++v) {
+            if (c->leaf_taxon[v] >= 0 || v == c->root) continue;
+            int lv = 0, n_leaf = 0, n_inner = 0;
+            for (int u : c->children[v]) {
+                if (c->leaf_taxon[u] >= 0) ++n_leaf; else { ++n_inner; lv = std::max(lv, level[u] + 1); }
+            }
+            if (n_leaf > kMaxExtChildren || n_inner > kMaxExtChildren) c->panel_extents = false;   // (a wide polytomy: no extents)
+            level[v] = lv;
+            max_level = std::max(max_level, lv);
+        }
+        if (c->panel_extents) {
+            std::vector<ExtNode> nodes;
+            for (int lv = 0; lv <= max_level; ++lv) {
+                cafe_ctx::ExtLevel L{(int)nodes.size(), 0, 0};
+                for (int v = 0; v < c->n_nodes; ++v) {
+                    if (level[v] != lv) continue;
+                    ExtNode nd{};
+                    nd.cols = (int32_t)(c->subtree_dedup ? c->pat_cols[v] : c->Fp);
+                    HIP_TRY(c, hipMalloc(&c->d_colext[v], sizeof(int32_t) * 2 * (size_t)c->Kmax * nd.cols));
+                    HIP_TRY(c, hipMalloc(&c->d_tileext[v], sizeof(int32_t) * 2 * (size_t)c->Kmax * (nd.cols / kBN)));
+                    nd.colext = c->d_colext[v];
+                    nd.tileext = c->d_tileext[v];
+                    nd.cnt = c->subtree_dedup ? c->d_leaf_cnt[v] : c->d_counts;
+                    nd.cnt_ld = c->subtree_dedup ? c->pat_cols[v] : c->Fp;
+                    for (int u : c->children[v]) {
+                        if (c->leaf_taxon[u] >= 0) {
+                            nd.leaf_pair[nd.n_leaf] = c->pair_of[u];
+                            nd.leaf_row[nd.n_leaf] = c->subtree_dedup ? c->leaf_rank[u] : c->leaf_taxon[u];
+                            ++nd.n_leaf;
+                        } else {
+                            nd.inner_pair[nd.n_inner] = c->pair_of[u];
+                            nd.inner_cols[nd.n_inner] = (int32_t)(c->subtree_dedup ? c->pat_cols[u] : c->Fp);
+                            nd.inner_map[nd.n_inner] = (!c->subtree_dedup || c->edge_identity[u]) ? nullptr : c->d_edge_map[u];
+                            nd.inner_colext[nd.n_inner] = c->d_colext[u];
+                            ++nd.n_inner;
+                        }
+                    }
+                    L.max_col_tiles = std::max(L.max_col_tiles, nd.cols / kBN);
+                    nodes.push_back(nd);
+                    ++L.count;
+                }
+                if (L.count) c->ext_levels.push_back(L);
+            }
+            HIP_TRY(c, hipMalloc(&c->d_ext_nodes, sizeof(ExtNode) * std::max<size_t>(1, nodes.size())));
+            HIP_TRY(c, hipMemcpy(c->d_ext_nodes, nodes.data(), sizeof(ExtNode) * nodes.size(), hipMemcpyHostToDevice));
+        }
+    }
+
 
     if (std::getenv("CAFE_DUMP_SCHEDULE")) {             // diagnostic: the launch list with its column counts
         for (auto& op : c->ops) {
@@ -1302,7 +1305,7 @@ int cafe_get_extents(cafe_ctx* ctx, int32_t node, int32_t category, int32_t* mat
     }
     if (n_tiles) *n_tiles = 0;
     if (panel_ext && !leaf && ctx->panel_extents && ctx->d_tileext[node]) {
-        const int nt = (int)(ctx->pat_cols[node] / kBN);
+        const int nt = (int)((ctx->subtree_dedup ? ctx->pat_cols[node] : ctx->Fp) / kBN);
         if (panel_ext_len < (size_t)2 * nt) { set_err(ctx, "cafe_get_extents: panel_ext too small"); return CAFE_ERR_ARGUMENT; }
         HIP_TRY(ctx, hipMemcpy(panel_ext, ctx->d_tileext[node] + (size_t)category * nt * 2, sizeof(int32_t) * 2 * nt, hipMemcpyDeviceToHost));
         if (n_tiles) *n_tiles = nt;

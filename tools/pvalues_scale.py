@@ -7,7 +7,7 @@ F = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 nsim = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 pb, _ = synth.make_problem(n_families=F)
 ctx = capi.Context(pb)
-for rep in range(2):
+for rep in range(4):
     t = time.time(); pv = ctx.pvalues(np.array([0.002]), n_simulations=nsim, seed=3 + rep); dt = time.time() - t
     print("pvalues: %.3f s for %d observed + %d x %d simulated families; significant at 0.05: %d; mean p %.3f"
           % (dt, F, pb.max_root_family_size, nsim, int((pv < 0.05).sum()), pv.mean()))
