@@ -201,6 +201,19 @@ def other_configs(args):
     out["config5_shape_two_lambdas_error_model"] = {"families": pb5.n_families, "ms_per_call": 1e3 * sec, "families_per_s": pb5.n_families / sec,
                                                     "neg_lnl": v, "rel_err_vs_reference": None}
     ctx.close()
+    # SURVEY 8d's generator parameters for config 4 (lambda_sim 0.003, root sizes capped at 480; the headline uses 0.002 / 300):
+    # larger families, fewer shared subtree patterns, wider non-zero extents.  Scored at the headline's lambda / alpha
+    # (at 0.003 / 1.5 the reference itself returns +inf on 100-taxon families: unscaled fp64 likelihoods underflow).
+    pb4, _ = synth.make_problem(n_taxa=args.taxa, n_families=args.families, max_count=args.max_count, lam_sim=0.003, root_cap=480)
+    K = args.categories
+    probs, mult = discrete_gamma(K, args.alpha)
+    pr4 = P.Params(lambdas=np.array([args.lam]), prior=P.prior_uniform(pb4.max_root_family_size), multipliers=mult, cat_probs=probs)
+    ctx = capi.Context(pb4, max_categories=K)
+    ctx.set_profiling(False)
+    sec, v = timed_calls(lambda: ctx.score(pr4, alpha=args.alpha), 3)
+    out["config4_survey_generator_lambda_sim_0.003_root_cap_480"] = {"families": pb4.n_families, "ms_per_call": 1e3 * sec, "families_per_s": pb4.n_families / sec,
+                                                                     "neg_lnl": v, "rel_err_vs_reference": None}
+    ctx.close()
     return out
 
 
