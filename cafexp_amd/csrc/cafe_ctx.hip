@@ -889,9 +889,12 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
                     g.gath_ld = c->factor_ld;
                     g.gath_map = c->d_edge_map[op.gath_child];
                 }
-                if (events && c->gemm_ev_used + 2 <= c->gemm_ev.size()) HIP_TRY(c, hipEventRecord(c->gemm_ev[c->gemm_ev_used++], s));
-                HIP_TRY(c, launch_prune_gemm(g, K, c->n_cu, s));
-                if (events && c->gemm_ev_used + 1 <= c->gemm_ev.size()) HIP_TRY(c, hipEventRecord(c->gemm_ev[c->gemm_ev_used++], s));
+                if (events && c->gemm_ev_used + 2 <= c->gemm_ev.size()) {       // start / stop events ride on the dispatch itself
+                    HIP_TRY(c, launch_prune_gemm(g, K, c->n_cu, s, c->gemm_ev[c->gemm_ev_used], c->gemm_ev[c->gemm_ev_used + 1]));
+                    c->gemm_ev_used += 2;
+                } else {
+                    HIP_TRY(c, launch_prune_gemm(g, K, c->n_cu, s));
+                }
                 c->stats.gemm_launches += 1;
                 c->gemm_launches_info.push_back({op.child, g.rows, gc, K, g.mi});
                 c->stats.gemm_flops_dense += 2.0 * rows * (c->M + 1) * (double)gc * K;

@@ -169,7 +169,8 @@ struct ReduceArgs {
 hipError_t launch_bd_matrix_build(const MatrixPool& pool, const SlotParam* d_slots, int n_slots, hipStream_t stream);
 hipError_t launch_bd_matrix_build_both(const MatrixPool& pool, const MatrixPool& kpool, const SlotParam* d_slots, const SlotParam* d_kslots,
                                        int n_slots, int n_kslots, hipStream_t stream);
-hipError_t launch_prune_gemm(const GemmArgs& a, int n_categories, int n_cu, hipStream_t stream);   // n_cu: compute units of the stream's device
+hipError_t launch_prune_gemm(const GemmArgs& a, int n_categories, int n_cu, hipStream_t stream, hipEvent_t ev_start = nullptr,
+                             hipEvent_t ev_stop = nullptr);   // n_cu: compute units of the stream's device; events: attached to the dispatch
 int prune_gemm_pick_mi(int rows, int n_col_tiles, int n_categories, int slots);     // row-tile height (in 16-row blocks)
 hipError_t launch_leaf_gather(const GatherArgs& a, int n_categories, hipStream_t stream);
 hipError_t launch_root_reduce(const ReduceArgs& a, hipStream_t stream);

@@ -32,6 +32,8 @@
 //    scratch memory (5x slower).  `make check` fails the build if a K2 instantiation uses scratch.
 #include <type_traits>
 
+#include <hip/hip_ext.h>
+
 #include "cafe_kernels.h"
 
 namespace cafe {
@@ -468,30 +470,37 @@ int prune_gemm_pick_mi(int rows, int n_col_tiles, int n_categories, int slots) {
     return best;
 }
 
+// ev0 / ev1 (both or neither): start / stop events attached to the dispatch itself (hipExtLaunchKernelGGL) -- the per-launch
+// timing of bench.py without two extra event-record packets around every launch
+#define CAFE_LAUNCH_GEMM(...)                                                                          \
+    do {                                                                                               \
+        if (ev0) hipExtLaunchKernelGGL((__VA_ARGS__), grid, block, 0, stream, ev0, ev1, 0, a);              \
+        else hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, stream, a);                               \
+    } while (0)
 template <int MI>
-static void launch_mi(const GemmArgs& a, dim3 grid, hipStream_t stream) {
+static void launch_mi(const GemmArgs& a, dim3 grid, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     const dim3 block(256);
     const int leaf = a.n_leaf ? (a.err ? 3 : 1) : (a.gath_src ? 2 : 0);
     if (leaf == 2) {                                       // gathered sibling factor: always the launch that creates the panel
-        hipLaunchKernelGGL((prune_gemm_kernel<MI, false, 2>), grid, block, 0, stream, a);
+        CAFE_LAUNCH_GEMM(prune_gemm_kernel<MI, false, 2>);
         return;
     }
     if (a.dst_ldt) {                                       // factor GEMM: transposed plain store
-        hipLaunchKernelGGL((prune_gemm_kernel<MI, false, 0, true>), grid, block, 0, stream, a);
+        CAFE_LAUNCH_GEMM(prune_gemm_kernel<MI, false, 0, true>);
         return;
     }
     if (a.mode) {
-        if (leaf == 3) hipLaunchKernelGGL((prune_gemm_kernel<MI, true, 3>), grid, block, 0, stream, a);
-        else if (leaf == 1) hipLaunchKernelGGL((prune_gemm_kernel<MI, true, 1>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((prune_gemm_kernel<MI, true, 0>), grid, block, 0, stream, a);
+        if (leaf == 3) CAFE_LAUNCH_GEMM(prune_gemm_kernel<MI, true, 3>);
+        else if (leaf == 1) CAFE_LAUNCH_GEMM(prune_gemm_kernel<MI, true, 1>);
+        else CAFE_LAUNCH_GEMM(prune_gemm_kernel<MI, true, 0>);
     } else {
-        if (leaf == 3) hipLaunchKernelGGL((prune_gemm_kernel<MI, false, 3>), grid, block, 0, stream, a);
-        else if (leaf == 1) hipLaunchKernelGGL((prune_gemm_kernel<MI, false, 1>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((prune_gemm_kernel<MI, false, 0>), grid, block, 0, stream, a);
+        if (leaf == 3) CAFE_LAUNCH_GEMM(prune_gemm_kernel<MI, false, 3>);
+        else if (leaf == 1) CAFE_LAUNCH_GEMM(prune_gemm_kernel<MI, false, 1>);
+        else CAFE_LAUNCH_GEMM(prune_gemm_kernel<MI, false, 0>);
     }
 }
 
-hipError_t launch_prune_gemm(const GemmArgs& a_in, int n_categories, int n_cu, hipStream_t stream) {
+hipError_t launch_prune_gemm(const GemmArgs& a_in, int n_categories, int n_cu, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     if (a_in.n_leaf > 1 || (a_in.n_leaf == 1 && a_in.err != nullptr && a_in.n_dev != 3)) return hipErrorInvalidValue;   // the schedule never asks for it
     if (a_in.gath_src && (a_in.n_leaf || a_in.mode || !a_in.gath_map || a_in.dst_ldt)) return hipErrorInvalidValue;
     if (a_in.dst_ldt && (a_in.n_leaf || a_in.mode)) return hipErrorInvalidValue;
@@ -513,12 +522,12 @@ hipError_t launch_prune_gemm(const GemmArgs& a_in, int n_categories, int n_cu, h
     dim3 grid(blocks, 1, 1);
     (void)hipGetLastError();
     switch (a.mi) {
-        case 4: launch_mi<4>(a, grid, stream); break;
-        case 5: launch_mi<5>(a, grid, stream); break;
-        case 6: launch_mi<6>(a, grid, stream); break;
-        case 7: launch_mi<7>(a, grid, stream); break;
-        case 8: launch_mi<8>(a, grid, stream); break;
-        case 9: launch_mi<9>(a, grid, stream); break;
+        case 4: launch_mi<4>(a, grid, stream, ev0, ev1); break;
+        case 5: launch_mi<5>(a, grid, stream, ev0, ev1); break;
+        case 6: launch_mi<6>(a, grid, stream, ev0, ev1); break;
+        case 7: launch_mi<7>(a, grid, stream, ev0, ev1); break;
+        case 8: launch_mi<8>(a, grid, stream, ev0, ev1); break;
+        case 9: launch_mi<9>(a, grid, stream, ev0, ev1); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
