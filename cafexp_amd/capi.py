@@ -69,7 +69,7 @@ EXPORTS = [
     "cafe_root_max", "cafe_reconstruct", "cafe_branch_probabilities", "cafe_pvalues", "cafe_debug_force_tile",
     "cafe_comm_unique_id", "cafe_comm_attach", "cafe_comm_detach", "cafe_shard_plan", "cafe_create_sharded",
     "cafe_sharded_destroy", "cafe_sharded_last_error", "cafe_sharded_score", "cafe_sharded_family_results",
-    "cafe_sharded_size", "cafe_sharded_context", "cafe_set_graphs", "cafe_executed_flops", "cafe_get_extents",
+    "cafe_sharded_size", "cafe_sharded_context", "cafe_set_graphs", "cafe_executed_flops", "cafe_get_extents", "cafe_debug_launch_flops", "cafe_debug_launch_ms",
 ]
 CAFE_COMM_ID_BYTES = 128
 
@@ -141,6 +141,8 @@ def load():
     L.cafe_set_graphs.argtypes = [C.c_void_p, C.c_int]
     L.cafe_get_extents.restype = C.c_int
     L.cafe_get_extents.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _i32p, C.c_size_t, _i32p, C.c_size_t, _i32p]
+    L.cafe_debug_launch_flops.restype = C.c_int
+    L.cafe_debug_launch_flops.argtypes = [C.c_void_p, _f64p, _f64p, _i32p, C.c_size_t]
     L.cafe_executed_flops.restype = C.c_int
     L.cafe_executed_flops.argtypes = [C.c_void_p, _f64p]
     L.cafe_comm_unique_id.restype = C.c_int
@@ -403,6 +405,13 @@ class Context:
         self._check(self._lib.cafe_get_extents(self._h, node, category, _p(m, _i32p), m.size, _p(pt, _i32p), pt.size, C.byref(nt)))
         leaf = self.problem.leaf_taxon[node] >= 0
         return (m[:n] if leaf else m[:(n - 1 + 15) // 16]), (pt[:nt.value] if nt.value else None)
+
+    def launch_flops(self):
+        """Per K2 launch of the last call: (executed flops, flops over all K tiles, tile height in 16-row blocks)."""
+        n = int(self.stats()["gemm_launches"])
+        ex, al, mi = np.zeros(n), np.zeros(n), np.zeros(n, dtype=np.int32)
+        self._check(self._lib.cafe_debug_launch_flops(self._h, _p(ex, _f64p), _p(al, _f64p), _p(mi, _i32p), n))
+        return ex, al, mi
 
     def executed_flops(self) -> float:
         """Flops the K2 launches of the last call really ran (K tiles outside matrix extent x panel extent are skipped)."""

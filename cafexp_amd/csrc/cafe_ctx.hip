@@ -1013,7 +1013,7 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bo
 // Flops the K2 launches of the last (profiled) call EXECUTED: a (row tile, column tile) pair runs only the K tiles inside
 // matrix extent x panel extent, so read the extents this call published and count, per launch, what its tiles ran.  Reads
 // the extents back (a few synchronous copies, milliseconds of host work): for measurement, once, not per call.
-double count_executed_flops(cafe_ctx* c) {
+double count_executed_flops(cafe_ctx* c, std::vector<double>* per_launch = nullptr) {
     if (!c->kpool.ext || c->gemm_launches_info.empty()) return c->stats.gemm_flops;
     // flops the K2 launches EXECUTED: K tiles outside a row tile's non-zero extent are skipped, so read the extents K1
     // published for this call and count, per launch, what its row tiles ran (same tile height as the launcher picks)
@@ -1025,6 +1025,8 @@ double count_executed_flops(cafe_ctx* c) {
         double executed = 0;
         std::vector<int32_t> bext;
         for (const auto& L : c->gemm_launches_info) {
+            const double before = executed;
+            if (per_launch) per_launch->push_back(0.0);
             const int mi = L.mi;
             const int bm = 16 * mi;
             const int n_ct = (int)(L.cols / kBN);
@@ -1050,6 +1052,7 @@ double count_executed_flops(cafe_ctx* c) {
                     (void)n_k;
                 }
             }
+            if (per_launch) per_launch->back() = executed - before;
         }
         return executed;
     }
@@ -1326,6 +1329,33 @@ int cafe_executed_flops(cafe_ctx* ctx, double* flops) {
     if (v < 0) { set_err(ctx, "cafe_executed_flops: reading the extents back failed"); return CAFE_ERR_DEVICE; }
     *flops = v;
     return CAFE_OK;
+}
+
+int cafe_debug_launch_ms(cafe_ctx* ctx, double* ms, size_t n) {      // diagnostic: HIP-event duration of every K2 launch of the last profiled call
+    if (!ctx || !ms) return CAFE_ERR_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+    for (size_t i = 0; i < n; ++i) {
+        float t = 0;
+        ms[i] = (2 * i + 1 < ctx->gemm_ev_used && hipEventElapsedTime(&t, ctx->gemm_ev[2 * i], ctx->gemm_ev[2 * i + 1]) == hipSuccess) ? t : 0.0;
+    }
+    return CAFE_OK;
+}
+
+int cafe_debug_launch_flops(cafe_ctx* ctx, double* executed, double* all_k_tiles, int32_t* tile_height, size_t n) {
+    if (!ctx || !executed) return CAFE_ERR_ARGUMENT;
+    if (!ctx->have_results || ctx->gemm_launches_info.empty()) { set_err(ctx, "cafe_debug_launch_flops: no call enqueued launch by launch"); return CAFE_ERR_STATE; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+    std::vector<double> v;
+    if (count_executed_flops(ctx, &v) < 0) { set_err(ctx, "cafe_debug_launch_flops: reading the extents back failed"); return CAFE_ERR_DEVICE; }
+    for (size_t i = 0; i < n && i < v.size(); ++i) {
+        const auto& L = ctx->gemm_launches_info[i];
+        executed[i] = v[i];
+        if (all_k_tiles) all_k_tiles[i] = 2.0 * L.rows * (ctx->M + 1) * (double)L.cols * L.K;
+        if (tile_height) tile_height[i] = L.mi;
+    }
+    return (int)std::min(n, v.size()) >= 0 ? CAFE_OK : CAFE_OK;
 }
 
 int cafe_set_graphs(cafe_ctx* ctx, int on) {

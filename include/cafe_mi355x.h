@@ -242,6 +242,10 @@ int cafe_get_stats(const cafe_ctx* ctx, cafe_stats* stats);
  * exact zero in them.  Reads the extents back and counts on the host (milliseconds): measurement only.  Needs a call that
  * was enqueued launch by launch (no graph replay). */
 int cafe_executed_flops(cafe_ctx* ctx, double* flops);
+/* diagnostic: the same per K2 launch of the last call, in launch order (executed[n], all_k_tiles[n] and tile_height[n] may be
+ * NULL); n = cafe_stats.gemm_launches */
+int cafe_debug_launch_flops(cafe_ctx* ctx, double* executed, double* all_k_tiles, int32_t* tile_height, size_t n);
+int cafe_debug_launch_ms(cafe_ctx* ctx, double* ms, size_t n);      /* HIP-event duration of each (profiling on) */
 int cafe_matrix_size(const cafe_ctx* ctx);
 /* 1: bracket the phases and every K2 launch with HIP events so that cafe_stats.ms_* are measured (bench.py does).
  * 0 (default): no events. */
