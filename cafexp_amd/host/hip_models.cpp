@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <iostream>
 #include <limits>
 
@@ -55,7 +56,7 @@ static void create_device_objects(const lambda* lam, const std::vector<const cla
     pb.n_deviations = n_deviations;
     pb.device = device; pb.flags = 0; pb.workspace_limit = 0;
     char err[512];
-    if (devices && devices->size() > 1) {
+    if (devices && !devices->empty() && out_sharded) {
         std::vector<int32_t> dev(devices->begin(), devices->end());
         *out_sharded = cafe_create_sharded(&pb, dev.data(), (int32_t)dev.size(), err, sizeof err);
         if (!*out_sharded) throw std::runtime_error(std::string("cafe_create_sharded: ") + err);
@@ -91,7 +92,10 @@ void hip_model_base::ensure_context(int max_categories) {
 }
 
 void hip_model_base::ensure_scorer(int max_categories) {
-    if (_devices.size() <= 1) { ensure_context(max_categories); return; }
+    // (CAFE_FORCE_SHARDED: the multi-GPU scorer also for one device -- its plan, worker thread, communicator and gather
+    // paths on a one-GPU box)
+    if (_devices.size() <= 1 && std::getenv("CAFE_FORCE_SHARDED")) { if (_devices.empty()) _devices.push_back(_device); }
+    else if (_devices.size() <= 1) { ensure_context(max_categories); return; }
     const int sig = _p_lambda->count() * 2 + (dynamic_cast<const multiple_lambda*>(_p_lambda) ? 1 : 0);
     if (_sharded && max_categories <= _sharded_categories && sig == _sharded_lambda_sig) return;
     _sharded_lambda_sig = sig;

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 #include <numeric>
 #include <stdexcept>
@@ -96,9 +97,9 @@ void hip_device_context::create(bool sharded, const lambda* p_lambda, const clad
     sig.categories = categories; sig.n_deviations = n_dev;
     if (sharded) {
         if (_sharded) { cafe_sharded_destroy(_sharded); _sharded = nullptr; }
-        std::vector<int32_t> devices(n_gpus);
-        std::iota(devices.begin(), devices.end(), 0);
-        _sharded = cafe_create_sharded(&pb, devices.data(), n_gpus, err, sizeof err);
+        std::vector<int32_t> devices(std::max(1, n_gpus));
+        std::iota(devices.begin(), devices.end(), n_gpus > 1 ? 0 : device);
+        _sharded = cafe_create_sharded(&pb, devices.data(), (int32_t)devices.size(), err, sizeof err);
         if (!_sharded) throw std::runtime_error(std::string("cafe_create_sharded: ") + err);
         _sharded_sig = sig;
     } else {
@@ -118,13 +119,19 @@ cafe_ctx* hip_device_context::ensure(const lambda* p_lambda, const clade* p_tree
 
 void hip_device_context::ensure_scorer(const lambda* p_lambda, const clade* p_tree, const std::vector<gene_family>* p_families,
                                        int max_family_size, int max_root_family_size, int categories, const error_model* p_error_model) {
-    if (n_gpus <= 1) { ensure(p_lambda, p_tree, p_families, max_family_size, max_root_family_size, categories, p_error_model); return; }
+    if (n_gpus <= 1 && !sharded_scorer()) { ensure(p_lambda, p_tree, p_families, max_family_size, max_root_family_size, categories, p_error_model); return; }
     if (!_sharded || !matches(_sharded_sig, p_lambda, p_tree, p_families, categories, p_error_model))
         create(true, p_lambda, p_tree, p_families, max_family_size, max_root_family_size, categories, p_error_model);
 }
 
+bool hip_device_context::sharded_scorer() const {
+    // several GPUs -- or CAFE_FORCE_SHARDED, which sends a single device through the same plan / worker thread / communicator
+    // / gather code (what a one-GPU box can exercise of it)
+    return n_gpus > 1 || std::getenv("CAFE_FORCE_SHARDED") != nullptr;
+}
+
 void hip_device_context::score(const cafe_params* params, double* neg_lnl) {
-    if (n_gpus > 1) {
+    if (sharded_scorer()) {
         if (cafe_sharded_score(_sharded, params, neg_lnl, nullptr) != CAFE_OK) throw std::runtime_error(std::string("cafe_sharded_score: ") + cafe_sharded_last_error(_sharded));
     } else if (cafe_score(_ctx, params, neg_lnl, nullptr) != CAFE_OK) {
         fail("cafe_score", _ctx);
@@ -132,7 +139,7 @@ void hip_device_context::score(const cafe_params* params, double* neg_lnl) {
 }
 
 bool hip_device_context::family_results(const cafe_family_out* out) {
-    return (n_gpus > 1 ? cafe_sharded_family_results(_sharded, out) : cafe_family_results(_ctx, out)) == CAFE_OK;
+    return (sharded_scorer() ? cafe_sharded_family_results(_sharded, out) : cafe_family_results(_ctx, out)) == CAFE_OK;
 }
 
 void hip_call_inputs::gather(root_equilibrium_distribution* p_prior, const std::map<int, int>& rootdist, const lambda* p_lambda,

@@ -60,6 +60,7 @@ public:
     //! what a scorer call runs on: the sharded scorer when n_gpus > 1, else the single-device context
     void ensure_scorer(const lambda* p_lambda, const clade* p_tree, const std::vector<gene_family>* p_families,
                        int max_family_size, int max_root_family_size, int categories, const error_model* p_error_model);
+    bool sharded_scorer() const;
     void score(const cafe_params* params, double* neg_lnl);              // throws std::runtime_error on a structural error
     bool family_results(const cafe_family_out* out);                     // false: the call was rejected (+inf), no results
     cafe_ctx* get() const { return _ctx; }

@@ -21,10 +21,11 @@ def test_host_unit_tests_pass():
     assert "0 failures" in out.stdout
 
 
-def _run(*args):
+def _run(*args, env=None):
     exe = os.path.join(HOST, "cafexp_hip")
     assert os.path.exists(exe), "cafexp_hip missing: run __graft_entry__.build()"
-    out = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=600,
+                         env=None if env is None else dict(os.environ, **env))
     assert out.returncode == 0, out.stderr
     d = json.loads(out.stdout.strip().splitlines()[-1])
     for k, v in list(d.items()):
@@ -174,3 +175,16 @@ def test_searches_reach_the_reference_programs_optimum(name, tmp_path):
     if name == "em":
         em = open(os.path.join(str(tmp_path), "Base_error_model.txt")).read().splitlines()
         assert em[:2] == e["error_model_txt"].splitlines()[:2]              # maxcnt / cntdiff header lines
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,args", [("mammals_gamma_k4_a2", ["-l", 0.005, "-k", 4, "-a", 2.0]), ("mammals_multilambda_err", ["-m", "0.01,0.05", "-y", LT, "-e", EM])])
+def test_driver_through_the_multi_gpu_scorer_on_one_device(golden, name, args):
+    """cafexp_hip --gpus N sends its scorer calls through cafe_create_sharded (family shards, a host thread per device, one
+    RCCL all-reduce per call).  With CAFE_FORCE_SHARDED the same code runs with a world of the one GPU this box has: the
+    plan, the worker thread, ncclCommInitAll / ncclAllReduce and the gather of per-family results back into table order."""
+    e = golden["scores"][name]
+    d = _run("-t", T, "-i", F, "--gpus", 1, *args, env={"CAFE_FORCE_SHARDED": "1"})
+    assert abs(d["neg_lnl"] - e["neg_lnl"]) / e["neg_lnl"] <= 1e-10
+    plain = _run("-t", T, "-i", F, *args)
+    assert abs(d["neg_lnl"] - plain["neg_lnl"]) <= 1e-13 * abs(plain["neg_lnl"])      # another family order inside the shard

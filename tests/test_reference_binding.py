@@ -36,11 +36,11 @@ def _fix(v):
     return v
 
 
-def run_hip(name):
+def run_hip(name, env=None):
     case = CASES[name]
     args = [HARNESS, case["job"], "device=hip"]
     args += ["%s=%s" % (k, os.path.join(DATA, v) if k in FILE_KEYS else v) for k, v in case.items() if k != "job"]
-    p = subprocess.run(args, capture_output=True, text=True, timeout=600)
+    p = subprocess.run(args, capture_output=True, text=True, timeout=600, env=None if env is None else dict(os.environ, **env))
     assert p.returncode == 0, p.stderr[-2000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     return {k: _fix(v) for k, v in json.loads(line).items()}
@@ -129,3 +129,21 @@ def test_reconstruction_and_reports_through_the_reference_writers(name, expected
         if key in want:
             assert got[key] == want[key], key
     assert sorted(got["clade_results_txt"].splitlines()) == sorted(want["clade_results_txt"].splitlines())   # ordered by heap address
+
+
+@pytest.mark.gpu
+@needs_harness
+@pytest.mark.parametrize("name", ["score_gamma4", "score_lambda_tree_error", "search_lambda"])
+def test_binding_through_the_multi_gpu_scorer_on_one_device(name, expected):
+    """hip_base_model / hip_gamma_model with n_gpus > 1 send their scorer calls through cafe_create_sharded; CAFE_FORCE_SHARDED
+    runs that path with a world of the one GPU of this box (plan, worker thread, ncclCommInitAll / ncclAllReduce, gather of
+    the per-family results into the reference's family order)."""
+    want, got = expected[name], run_hip(name, env={"CAFE_FORCE_SHARDED": "1"})
+    if "neg_lnl" in want:
+        assert abs(got["neg_lnl"] - want["neg_lnl"]) <= 1e-10 * abs(want["neg_lnl"])
+        for key in ("family_lnl", "category_likelihood", "family_likelihood"):
+            if key in want:
+                np.testing.assert_allclose(got[key], want[key], rtol=1e-9, atol=0, err_msg=key)
+    else:
+        assert got["iterations"] == want["iterations"]
+        np.testing.assert_allclose(got["values"], want["values"], rtol=1e-7)
