@@ -136,6 +136,7 @@ struct cafe_ctx {
     // mutually independent nodes (a node's level = 1 + its deepest interior child's); per node and category the per-column
     // and per-128-column-tile intervals outside which the panel is exactly zero
     bool panel_extents = false;
+    bool no_asm_skip = false;                             // CAFE_NO_ASM_SKIP: the assemble pass writes every row (diagnostic)
     cafe::ExtNode* d_ext_nodes = nullptr;
     std::vector<int32_t*> d_colext, d_tileext;            // [n_nodes] (interior non-root nodes only)
     struct ExtLevel { int first, count, max_col_tiles; };

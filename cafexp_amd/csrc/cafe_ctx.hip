@@ -606,6 +606,7 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     // (one column per family at every node -- CAFE_FLAG_NO_SUBTREE_DEDUP, device-written counts -- works the same way as long
     // as the families fit one column chunk: every edge is the identity and the counts are the family table itself)
     c->panel_extents = (c->subtree_dedup || c->stats.n_chunks == 1) && c->kpool.ext && c->pool.ext && !std::getenv("CAFE_NO_PANEL_EXTENTS");
+    c->no_asm_skip = std::getenv("CAFE_NO_ASM_SKIP") != nullptr;
     if (c->panel_extents) {
         std::vector<int> level(c->n_nodes, -1);
         int max_level = -1;
@@ -857,6 +858,8 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
                     g.ld_src[j] = c->factor_ld;
                     g.map[j] = c->d_edge_map[op.src_child[j]];
                 }
+                // (the root's vector is read whole by the reduction and has no extent record)
+                g.tileext = c->panel_extents && op.n_src > 0 && !op.to_root && !c->no_asm_skip ? c->d_tileext[op.parent] : nullptr;
                 HIP_TRY(c, launch_leaf_gather(g, K, s));
             } else {
                 GemmArgs g{};

@@ -117,6 +117,9 @@ struct GatherArgs {
     const double* src[2];
     int64_t ld_src[2];
     const int32_t* map[2];
+    // [category][ld / 128][2] zero extent of each 128-column tile of dst (extents.hip), or nullptr: rows outside it (rounded
+    // out to K2's 16-row K tiles) are neither read nor written by the assemble pass
+    const int32_t* tileext;
 };
 
 // Zero extents of the likelihood panels (extents.hip).  One ExtNode per interior non-root node, static per context.

@@ -184,6 +184,14 @@ __global__ __launch_bounds__(256) void assemble_t_kernel(const GatherArgs a) {
     const int i0 = blockIdx.y * kAsmT;                       // first transposed row index: panel row = index - toff
     const int toff = 15 + a.row_off;
     const int tid = threadIdx.x;
+    if (a.tileext) {
+        // Rows outside the zero extent of the 128-column tile (extents.hip) are exact zeros that K2 never reads: it stages only
+        // the K tiles (16 rows each) that meet the extent, or the tile at its first row when nothing does.  Leave them alone.
+        const int32_t* te = a.tileext + ((int64_t)cat * (a.ld / kBN) + (c0 / kBN)) * 2;
+        int lo = te[0], hi = te[1];
+        if (hi < lo) { lo = 0; hi = 0; }
+        if (i0 + kAsmT - 1 - toff < (lo & ~15) || i0 - toff > (hi | 15)) return;
+    }
     // ---- phase A: 64 columns x 64 indices of each factor, 16 bytes per lane, 32 lanes per column
     {
         const int seg = tid & 31, cl = tid >> 5;             // column cl + 8 * i of the tile

@@ -146,12 +146,15 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
 #pragma unroll
             for (int b = 0; b < MI; ++b)
                 if (b0 + b < a.pool.ext_blocks) { lo = min(lo, e[2 * b]); hi = max(hi, e[2 * b + 1]); }
+            int zlo = 0;                                    // a K tile that is safe to run when nothing needs to be
             if (a.bext) {                                   // and the rows of this column tile of B that are not all zero
                 const int32_t* be = a.bext + ((int64_t)x.cat * a.n_col_tiles + ct) * 2;
                 lo = max(lo, be[0]);
                 hi = min(hi, be[1]);
+                if (be[1] >= be[0]) zlo = be[0];            // (rows of B outside its tile extent may never have been written:
+                                                            // the assemble pass leaves them out, leaf_reduce.hip)
             }
-            if (hi < lo) { lo = 0; hi = 0; }                // an all-zero tile still runs one K tile (every product in it has a
+            if (hi < lo) { lo = zlo; hi = zlo; }            // an all-zero tile still runs one K tile (every product in it has a
                                                             // zero factor): the panel must receive its zeros
             hi = min(hi, a.k_valid - 1);
             x.kt0 = __builtin_amdgcn_readfirstlane(lo / kBK);

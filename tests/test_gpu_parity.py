@@ -637,3 +637,33 @@ def test_zero_extents_contain_every_nonzero_and_change_no_bit(capi, oracle, monk
     sub = dataclasses.replace(pb, counts=pb.counts[sel].copy(), family_ids=[pb.family_ids[i] for i in sel])
     _, cat, fam = oracle.score_gamma(sub, pr, per_family=True)
     assert np.max(np.abs(r1["family_likelihood"][sel] / fam - 1)) <= 1e-11
+
+
+@pytest.mark.gpu
+def test_assemble_pass_skips_rows_outside_the_extent_without_changing_a_bit(capi, oracle, monkeypatch):
+    """The assemble pass (leaf_reduce.hip) neither reads nor writes the rows of a panel that lie outside the zero extent of
+    their 128-column tile, so those rows keep whatever an earlier call -- or another node that used the same buffer -- left
+    there.  K2 must never look at them: one context scored with wide, narrow and wide extents in turn gives, call for call,
+    the bits of a fresh context and of a context that writes every row (CAFE_NO_ASM_SKIP)."""
+    pb, _ = synth.make_problem(n_taxa=16, n_families=1500, max_count=250, lam_sim=0.003, seed=11, root_cap=120)
+    assert pb.matrix_size >= 256
+    probs, mult = oracle.discrete_gamma(3, 0.9)
+    lams = [0.006, 0.0004, 0.006, 0.0015]
+    prs = [P.Params(lambdas=np.array([l]), prior=P.prior_uniform(pb.max_root_family_size), multipliers=mult, cat_probs=probs)
+           for l in lams]
+    reused = capi.Context(pb, max_categories=3)
+    assert reused.stats()["n_assemble_passes"] > 0
+    got = [reused.score(pr, alpha=0.9, per_family=True) for pr in prs]
+    for pr, (v, r) in zip(prs, got):
+        fresh = capi.Context(pb, max_categories=3)
+        v2, r2 = fresh.score(pr, alpha=0.9, per_family=True)
+        assert v == v2
+        for key in r:
+            assert np.array_equal(r[key], r2[key]), key
+    monkeypatch.setenv("CAFE_NO_ASM_SKIP", "1")
+    full = capi.Context(pb, max_categories=3)
+    for pr, (v, r) in zip(prs, got):
+        v2, r2 = full.score(pr, alpha=0.9, per_family=True)
+        assert v == v2
+        for key in r:
+            assert np.array_equal(r[key], r2[key]), key
