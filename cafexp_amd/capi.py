@@ -69,7 +69,7 @@ EXPORTS = [
     "cafe_root_max", "cafe_reconstruct", "cafe_branch_probabilities", "cafe_pvalues", "cafe_debug_force_tile",
     "cafe_comm_unique_id", "cafe_comm_attach", "cafe_comm_detach", "cafe_shard_plan", "cafe_create_sharded",
     "cafe_sharded_destroy", "cafe_sharded_last_error", "cafe_sharded_score", "cafe_sharded_family_results",
-    "cafe_sharded_size", "cafe_sharded_context", "cafe_set_graphs", "cafe_executed_flops", "cafe_get_extents", "cafe_debug_launch_flops", "cafe_debug_launch_ms",
+    "cafe_sharded_size", "cafe_sharded_context", "cafe_set_graphs", "cafe_executed_flops", "cafe_get_extents", "cafe_debug_launch_flops", "cafe_debug_launch_ms", "cafe_debug_plan_check",
 ]
 CAFE_COMM_ID_BYTES = 128
 
@@ -412,6 +412,15 @@ class Context:
         ex, al, mi = np.zeros(n), np.zeros(n), np.zeros(n, dtype=np.int32)
         self._check(self._lib.cafe_debug_launch_flops(self._h, _p(ex, _f64p), _p(al, _f64p), _p(mi, _i32p), n))
         return ex, al, mi
+
+    def plan_check(self):
+        """(launches of the last call that ran from planned tile lists, worst modelled workgroup load / mean); raises when a
+        list does not cover its launch's tiles exactly once with the K ranges the extents give."""
+        n, w = C.c_int32(), C.c_double()
+        self._lib.cafe_debug_plan_check.restype = C.c_int
+        self._lib.cafe_debug_plan_check.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+        self._check(self._lib.cafe_debug_plan_check(self._h, C.byref(n), C.byref(w)))
+        return n.value, w.value
 
     def executed_flops(self) -> float:
         """Flops the K2 launches of the last call really ran (K tiles outside matrix extent x panel extent are skipped)."""

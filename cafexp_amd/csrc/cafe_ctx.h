@@ -146,6 +146,15 @@ struct cafe_ctx {
     // them on the device; a copy lands in h_ext while the call's K2 launches run): the parameters of consecutive scorer
     // calls are close, and the choice only affects speed, never a bit of the result
     int32_t* h_ext = nullptr;                // pinned [max_kslots][ext_blocks][2]
+    // tile lists of the K2 launches (tile_plan_kernel): one descriptor per launch, rebuilt per call (the tile heights may
+    // change), uploaded when it differs from the last upload
+    bool use_plan = false;
+    int plan_fixed = 4;                      // cost of an output tile beyond its K loop, in K tiles (fitted: DESIGN.md; CAFE_PLAN_FIXED)
+    int2* d_plan = nullptr;
+    size_t plan_entries = 0;
+    cafe::PlanLaunch* d_plan_desc = nullptr;
+    cafe::PlanLaunch* h_plan_desc = nullptr;        // pinned
+    std::vector<cafe::PlanLaunch> plan_desc_sent;
     bool h_ext_valid = false;
     int h_ext_K = 0;                         // categories of the call the copy belongs to
 

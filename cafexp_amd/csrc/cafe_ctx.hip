@@ -310,6 +310,8 @@ void free_device(cafe_ctx* c) {
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_result) hipHostFree(c->h_result);
     if (c->h_ext) hipHostFree(c->h_ext);
+    hipFree(c->d_plan); hipFree(c->d_plan_desc);
+    if (c->h_plan_desc) hipHostFree(c->h_plan_desc);
     if (c->ev_upload) hipEventDestroy(c->ev_upload);
     for (auto& e : c->ev) if (e) hipEventDestroy(e);
     for (auto& e : c->gemm_ev) hipEventDestroy(e);
@@ -659,6 +661,32 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     }
 
 
+    // tile lists for the K2 launches: room for the tallest list any tile height can ask for
+    c->use_plan = c->kpool.ext && c->stats.n_chunks == 1 && !std::getenv("CAFE_NO_PLAN");
+    if (const char* e = std::getenv("CAFE_PLAN_FIXED")) c->plan_fixed = std::max(0, atoi(e));
+    if (c->use_plan) {
+        size_t entries = 0, n_gemm = 0;
+        for (const Op& op : c->ops) {
+            if (op.type != 1) continue;
+            ++n_gemm;
+            const int64_t gc = c->subtree_dedup ? c->pat_cols[op.child] : c->chunk_cols;
+            const int rows = op.to_root ? c->R : c->M;
+            size_t worst = 0;
+            for (int mi = 4; mi <= 9; ++mi) {
+                const int nrt = (rows + 16 * mi - 1) / (16 * mi), nct = (int)(gc / kBN);
+                const int nlb = prune_gemm_blocks(c->Kmax, nct, nrt, c->n_cu) / 8;
+                const int64_t tiles = (((int64_t)c->Kmax * nct + 7) / 8) * nrt;
+                (void)nlb;
+                worst = std::max(worst, (size_t)8 * (size_t)(tiles + 64));      // >= 8 * nlb * ceil(tiles / nlb) for any K <= Kmax
+            }
+            entries += worst;
+        }
+        c->plan_entries = entries;
+        HIP_TRY(c, hipMalloc(&c->d_plan, sizeof(int2) * std::max<size_t>(1, entries)));
+        HIP_TRY(c, hipMalloc(&c->d_plan_desc, sizeof(PlanLaunch) * std::max<size_t>(1, n_gemm)));
+        HIP_TRY(c, hipHostMalloc(&c->h_plan_desc, sizeof(PlanLaunch) * std::max<size_t>(1, n_gemm), hipHostMallocDefault));
+    }
+
     if (std::getenv("CAFE_DUMP_SCHEDULE")) {             // diagnostic: the launch list with its column counts
         for (auto& op : c->ops) {
             const int64_t pc = c->subtree_dedup ? c->pat_cols[op.parent] : c->chunk_cols;
@@ -796,7 +824,7 @@ int pick_tile_height(const cafe_ctx* c, const int32_t* ext, int child, int rows,
 // The device work of one call, enqueued on `s` (or recorded into a graph being captured on `s`): parameter upload,
 // K1, the schedule (K2 / K3 launches), K4, the final sum into d_out.  Everything that changes between calls of the
 // same shape travels through the parameter block; kernel arguments depend only on (reduction, K, error model).
-int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, double* d_out, hipStream_t s, bool events) {
+int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, double* d_out, hipStream_t s, bool events, bool capturing) {
     c->stats.gemm_flops = c->stats.gemm_bytes = c->stats.gemm_flops_per_family = c->stats.gemm_flops_dense = 0;
     c->stats.gemm_launches = 0;
     HIP_TRY(c, hipMemcpyAsync(c->d_params, c->h_stage, c->params_bytes, hipMemcpyHostToDevice, s));
@@ -821,6 +849,53 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
         for (const auto& L : c->ext_levels) {
             ea.first = L.first; ea.count = L.count;
             HIP_TRY(c, launch_node_extents(ea, L.max_col_tiles, K, s));
+        }
+    }
+
+    // ---- tile heights of the K2 launches, and (one column chunk, extents on) their tile lists
+    std::vector<int> op_mi(c->ops.size(), 0);
+    std::vector<const int2*> op_plan(c->ops.size(), nullptr);
+    std::vector<int> op_rounds(c->ops.size(), 0);
+    {
+        size_t used = 0;
+        int n_desc = 0;
+        for (size_t i = 0; i < c->ops.size(); ++i) {
+            const Op& op = c->ops[i];
+            if (op.type != 1) continue;
+            const int64_t gc = c->subtree_dedup ? c->pat_cols[op.child] : std::min<int64_t>(c->chunk_cols, c->Fp);
+            const int rows = op.to_root ? c->R : c->M;
+            const int nct = (int)(gc / kBN);
+            int mi = c->force_mi;                           // 0: picked per launch
+            if (!mi && have_ext) mi = pick_tile_height(c, prev_ext.data(), op.child, rows, nct, K);
+            if (!mi) mi = prune_gemm_pick_mi(rows, nct, K, 2 * c->n_cu / 8 * 8);   // no extents yet: whole rounds x height
+            op_mi[i] = mi;
+            if (!c->use_plan || capturing) continue;      // (a captured graph would replay one shared descriptor block)
+            const int nrt = (rows + 16 * mi - 1) / (16 * mi);
+            const int nlb = prune_gemm_blocks(K, nct, nrt, c->n_cu) / 8;
+            const int64_t tiles = (((int64_t)K * nct + 7) / 8) * nrt;
+            const int rounds = (int)((tiles + nlb - 1) / nlb);
+            const size_t need = (size_t)8 * nlb * rounds;
+            if (used + need > c->plan_entries) continue;    // (cannot happen: the room was sized for the tallest list)
+            PlanLaunch& d = c->h_plan_desc[n_desc];
+            d = PlanLaunch{};
+            d.aext = c->kpool.ext; d.ext_blocks = c->kpool.ext_blocks;
+            for (int k = 0; k < K; ++k) d.slot[k] = c->slot_of[(size_t)op.child * c->Kmax + k];
+            d.bext = c->panel_extents ? c->d_tileext[op.child] : nullptr;
+            d.mi = mi; d.n_row_tiles = nrt; d.n_col_tiles = nct; d.n_categories = K; d.k_valid = c->M + 1;
+            d.blocks_per_xcd = nlb; d.rounds = rounds; d.plan = c->d_plan + used;
+            d.fixed = c->plan_fixed;
+            op_plan[i] = d.plan; op_rounds[i] = rounds;
+            used += need;
+            ++n_desc;
+        }
+        if (n_desc > 0) {
+            const bool same = c->plan_desc_sent.size() == (size_t)n_desc &&
+                              std::memcmp(c->plan_desc_sent.data(), c->h_plan_desc, sizeof(PlanLaunch) * n_desc) == 0;
+            if (!same) {
+                HIP_TRY(c, hipMemcpyAsync(c->d_plan_desc, c->h_plan_desc, sizeof(PlanLaunch) * n_desc, hipMemcpyHostToDevice, s));
+                c->plan_desc_sent.assign(c->h_plan_desc, c->h_plan_desc + n_desc);
+            }
+            HIP_TRY(c, launch_tile_plan(c->d_plan_desc, n_desc, s));
         }
     }
 
@@ -872,9 +947,9 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
                 g.out_off = op.to_root ? 0 : 1;
                 g.mode = op.mode;
                 g.dst_ldt = op.to_factor ? c->factor_ld : 0;
-                g.mi = c->force_mi;                         // 0: launch_prune_gemm picks the tile height for this launch
-                if (!g.mi && have_ext) g.mi = pick_tile_height(c, prev_ext.data(), op.child, g.rows, (int)(gc / kBN), K);
-                if (!g.mi) g.mi = prune_gemm_pick_mi(g.rows, (int)(gc / kBN), K, 2 * c->n_cu / 8 * 8);   // no extents yet: whole rounds x height
+                g.mi = op_mi[&op - c->ops.data()];
+                g.plan = op_plan[&op - c->ops.data()];
+                g.plan_rounds = op_rounds[&op - c->ops.data()];
                 g.n_row_tiles = (g.rows + 16 * g.mi - 1) / (16 * g.mi);
                 g.n_col_tiles = (int)(gc / kBN);
                 g.stamps = (c->stamps_launch < 0 || c->stamps_launch == (long)c->stats.gemm_launches) ? c->d_stamps : nullptr;
@@ -978,7 +1053,7 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bo
 
     const bool graph_ok = c->use_graph && !c->profile && !c->d_stamps && c->force_mi == 0;
     if (!graph_ok) {
-        const int rc = record_call(c, K, gamma, rootmax, use_err, d_out, s, c->profile != 0);
+        const int rc = record_call(c, K, gamma, rootmax, use_err, d_out, s, c->profile != 0, false);
         if (rc != CAFE_OK) return rc;
     } else {
         const int key = (rootmax ? 2 : (gamma ? 1 : 0)) + 4 * K;
@@ -987,7 +1062,7 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bo
             // capture on the context's own stream (idle: calls are sequential), replay on the caller's
             hipGraph_t graph = nullptr;
             HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-            const int rc = record_call(c, K, gamma, rootmax, use_err, c->d_result, c->stream, false);
+            const int rc = record_call(c, K, gamma, rootmax, use_err, c->d_result, c->stream, false, true);
             const hipError_t ee = hipStreamEndCapture(c->stream, &graph);
             if (rc != CAFE_OK) { if (graph) (void)hipGraphDestroy(graph); c->graphs.erase(key); return rc; }
             if (ee != hipSuccess || !graph) { c->graphs.erase(key); set_err(c, "hipStreamEndCapture failed: %s", hipGetErrorString(ee)); return CAFE_ERR_DEVICE; }
@@ -1331,6 +1406,73 @@ int cafe_executed_flops(cafe_ctx* ctx, double* flops) {
     const double v = count_executed_flops(ctx);
     if (v < 0) { set_err(ctx, "cafe_executed_flops: reading the extents back failed"); return CAFE_ERR_DEVICE; }
     *flops = v;
+    return CAFE_OK;
+}
+
+// diagnostic / test: read the tile lists of the last call back and check them against the extents -- every tile of every
+// planned launch exactly once, with the K range the kernel's own decode would work out, nothing behind the end of a list.
+// *n_planned: launches with a plan; *worst_load: largest planned workgroup load over the mean load of its XCD.
+int cafe_debug_plan_check(cafe_ctx* ctx, int32_t* n_planned, double* worst_load) {
+    if (!ctx) return CAFE_ERR_ARGUMENT;
+    if (n_planned) *n_planned = 0;
+    if (worst_load) *worst_load = 1.0;
+    if (!ctx->use_plan || ctx->plan_desc_sent.empty()) return CAFE_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+    const int nb = ctx->kpool.ext_blocks;
+    std::vector<int32_t> aext((size_t)2 * ctx->max_kslots * nb), bext;
+    HIP_TRY(ctx, hipMemcpy(aext.data(), ctx->kpool.ext, aext.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<int2> plan;
+    double worst = 1.0;
+    for (const PlanLaunch& L : ctx->plan_desc_sent) {
+        const int nlb = L.blocks_per_xcd;
+        plan.resize((size_t)8 * nlb * L.rounds);
+        HIP_TRY(ctx, hipMemcpy(plan.data(), L.plan, plan.size() * sizeof(int2), hipMemcpyDeviceToHost));
+        if (L.bext) {
+            bext.resize((size_t)2 * L.n_categories * L.n_col_tiles);
+            HIP_TRY(ctx, hipMemcpy(bext.data(), L.bext, bext.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        }
+        for (int x = 0; x < 8; ++x) {
+            const int my_pairs = (L.n_categories * L.n_col_tiles - x + 7) >> 3;
+            const int n_tiles = my_pairs * L.n_row_tiles;
+            std::vector<char> seen((size_t)n_tiles, 0);
+            double total = 0, top = 0;
+            for (int w = 0; w < nlb; ++w) {
+                bool ended = false;
+                double load = 0;
+                for (int r = 0; r < L.rounds; ++r) {
+                    const int2 e = plan[((size_t)x * nlb + w) * L.rounds + r];
+                    if (e.y == 0) { ended = true; if (e.x != 0) goto bad; continue; }
+                    if (ended || e.x < 0 || e.x >= n_tiles || seen[e.x]) goto bad;
+                    seen[e.x] = 1;
+                    const int row_tile = e.x % L.n_row_tiles, pair = x + 8 * (e.x / L.n_row_tiles);
+                    const int ct = pair % L.n_col_tiles, cat = pair / L.n_col_tiles, b0 = row_tile * L.mi;
+                    const int32_t* a = aext.data() + ((size_t)L.slot[cat] * nb + b0) * 2;
+                    int lo = 0x7fffffff, hi = -1, zlo = 0;
+                    for (int b = 0; b < L.mi && b0 + b < nb; ++b) { lo = std::min(lo, a[2 * b]); hi = std::max(hi, a[2 * b + 1]); }
+                    if (L.bext) {
+                        const int32_t* be = bext.data() + ((size_t)cat * L.n_col_tiles + ct) * 2;
+                        lo = std::max(lo, be[0]); hi = std::min(hi, be[1]);
+                        if (be[1] >= be[0]) zlo = be[0];
+                    }
+                    if (hi < lo) { lo = zlo; hi = zlo; }
+                    hi = std::min(hi, L.k_valid - 1);
+                    if ((e.y >> 16) != lo / kBK || (e.y & 0xFFFF) != hi / kBK - lo / kBK + 1) goto bad;
+                    load += (e.y & 0xFFFF) + L.fixed;
+                }
+                total += load;
+                top = std::max(top, load);
+            }
+            for (char v : seen) if (!v) goto bad;
+            if (total > 0) worst = std::max(worst, top / (total / nlb));
+        }
+        if (n_planned) *n_planned += 1;
+        continue;
+    bad:
+        set_err(ctx, "cafe_debug_plan_check: the tile lists of a launch do not match its extents");
+        return CAFE_ERR_STATE;
+    }
+    if (worst_load) *worst_load = worst;
     return CAFE_OK;
 }
 

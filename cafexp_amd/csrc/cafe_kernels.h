@@ -90,7 +90,30 @@ struct GemmArgs {
     // > 0: this launch is a factor GEMM and stores transposed, dst[column][16 - out_off + panel row], dst_ldt rows per
     // column (see prune_gemm.hip)
     int32_t dst_ldt;
+    // Tile lists laid out by tile_plan_kernel (extents.hip) for this launch, or nullptr: workgroup `local` of XCD `xcd` runs
+    // the tiles plan[(xcd * blocks_per_xcd + local) * plan_rounds + i], i = 0, 1, ... until an entry with y == 0.
+    // x: index of the tile in the XCD's list (pair-major, row tile fastest), y: first K tile << 16 | number of K tiles.
+    const int2* plan;
+    int32_t plan_rounds;
 };
+
+// One K2 launch as the tile planner sees it.  K loops of unequal length (zero extents) make a fixed deal of tiles uneven:
+// the planner deals each round of tiles (one per workgroup of the XCD, in the order the fixed deal would run them, so the
+// row tiles of a column tile still run together) longest tile to least-loaded workgroup.
+struct PlanLaunch {
+    const int32_t* aext;            // k-major pool extents (MatrixPool::ext)
+    int32_t ext_blocks;
+    int32_t slot[kMaxCategories];
+    const int32_t* bext;            // GemmArgs::bext
+    int32_t mi, n_row_tiles, n_col_tiles, n_categories, k_valid;
+    int32_t blocks_per_xcd;         // workgroups of the launch / 8
+    int32_t rounds;                 // list length per workgroup
+    int32_t fixed;                  // what an output tile costs beyond its K loop, in K tiles
+    int2* plan;                     // [8][blocks_per_xcd][rounds]
+};
+hipError_t launch_tile_plan(const PlanLaunch* d_launches, int n_launches, hipStream_t stream);
+// workgroups of a K2 launch (a multiple of 8): two per CU, fewer when the launch has fewer tiles
+int prune_gemm_blocks(int n_categories, int n_col_tiles, int n_row_tiles, int n_cu);
 
 struct GatherArgs {
     MatrixPool pool;

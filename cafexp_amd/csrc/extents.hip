@@ -73,4 +73,68 @@ hipError_t launch_node_extents(const ExtArgs& a, int max_col_tiles, int n_catego
     return hipGetLastError();
 }
 
+// Tile lists of the K2 launches of a call (PlanLaunch, cafe_kernels.h): one wave per (XCD, launch), lane = workgroup.
+// Cost of a tile = its K tiles + PlanLaunch::fixed.
+__global__ __launch_bounds__(64) void tile_plan_kernel(const PlanLaunch* __restrict__ launches) {
+    const PlanLaunch& L = launches[blockIdx.y];
+    const int xcd = blockIdx.x, lane = threadIdx.x;
+    const int nlb = L.blocks_per_xcd;
+    const int my_pairs = (L.n_categories * L.n_col_tiles - xcd + 7) >> 3;
+    const int n_tiles = my_pairs * L.n_row_tiles;
+    __shared__ int s_load[64], s_cost[64], s_who[64];
+    s_load[lane] = 0;
+    __syncthreads();
+    for (int r = 0; r < L.rounds; ++r) {
+        const int t = r * nlb + lane;
+        const bool valid = lane < nlb && t < n_tiles;
+        int kt0 = 0, nkt = 0;
+        if (valid) {                                       // (the same arithmetic as the kernel's own decode, prune_gemm.hip)
+            const int row_tile = t % L.n_row_tiles;
+            const int pair = xcd + 8 * (t / L.n_row_tiles);
+            const int ct = pair % L.n_col_tiles, cat = pair / L.n_col_tiles;
+            const int b0 = row_tile * L.mi;
+            const int32_t* e = L.aext + ((int64_t)L.slot[cat] * L.ext_blocks + b0) * 2;
+            int lo = 0x7fffffff, hi = -1;
+            for (int b = 0; b < L.mi; ++b)
+                if (b0 + b < L.ext_blocks) { lo = min(lo, e[2 * b]); hi = max(hi, e[2 * b + 1]); }
+            int zlo = 0;
+            if (L.bext) {
+                const int32_t* be = L.bext + ((int64_t)cat * L.n_col_tiles + ct) * 2;
+                lo = max(lo, be[0]);
+                hi = min(hi, be[1]);
+                if (be[1] >= be[0]) zlo = be[0];
+            }
+            if (hi < lo) { lo = zlo; hi = zlo; }
+            hi = min(hi, L.k_valid - 1);
+            kt0 = lo / kBK;
+            nkt = hi / kBK - lo / kBK + 1;
+        }
+        const int cst = valid ? nkt + L.fixed : -1;
+        const int mine = s_load[lane];
+        s_cost[lane] = cst;
+        __syncthreads();
+        int crank = 0, lrank = 0;                          // longest tile first; least-loaded workgroup first (ties: by index)
+        for (int k = 0; k < nlb; ++k) {
+            const int ck = s_cost[k], lk = s_load[k];
+            crank += (ck > cst || (ck == cst && k < lane)) ? 1 : 0;
+            lrank += (lk < mine || (lk == mine && k < lane)) ? 1 : 0;
+        }
+        if (lane < nlb) s_who[lrank] = lane;
+        __syncthreads();
+        if (lane < nlb) {
+            const int w = s_who[crank];
+            L.plan[((int64_t)xcd * nlb + w) * L.rounds + r] = valid ? make_int2(t, (kt0 << 16) | nkt) : make_int2(0, 0);
+            if (valid) s_load[w] += cst;
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_tile_plan(const PlanLaunch* d_launches, int n_launches, hipStream_t stream) {
+    if (n_launches <= 0) return hipSuccess;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(tile_plan_kernel, dim3(8, n_launches), dim3(64), 0, stream, d_launches);
+    return hipGetLastError();
+}
+
 }  // namespace cafe

@@ -123,7 +123,17 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
         int kt0, nkt;                                       // K tiles [kt0, kt0 + nkt) hold this row tile's non-zero A entries
     };
     const int32_t* __restrict__ ext = a.pool.ext;
-    auto decode = [&](int t) -> Tile {
+    // The workgroup's tiles: entry i of its planned list (tile_plan_kernel: x = index in the XCD's list, y = first K tile << 16
+    // | K tiles), or, without a plan, every n_local_blocks-th tile of the XCD's list (y = -1: the extent is worked out here).
+    // y == 0 ends the list.  All scalar.
+    const int2* __restrict__ mylist = a.plan ? a.plan + ((int64_t)xcd * n_local_blocks + local) * a.plan_rounds : nullptr;
+    auto entry = [&](int i) -> int2 {
+        if (mylist) return i < a.plan_rounds ? mylist[i] : make_int2(0, 0);
+        const int t = local + i * n_local_blocks;
+        return t < n_tiles ? make_int2(t, -1) : make_int2(0, 0);
+    };
+    auto decode = [&](int2 en) -> Tile {
+        const int t = en.x;
         Tile x;
         x.row_tile = t % a.n_row_tiles;
         const int pair = xcd + 8 * (t / a.n_row_tiles);
@@ -139,7 +149,10 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
         // skipping it leaves every accumulator bit as it is and saves its MFMAs and the B rows it would have staged.
         x.kt0 = 0;
         x.nkt = n_k;
-        if (ext) {
+        if (en.y != -1) {
+            x.kt0 = __builtin_amdgcn_readfirstlane(en.y >> 16);
+            x.nkt = __builtin_amdgcn_readfirstlane(en.y & 0xFFFF);
+        } else if (ext) {
             const int b0 = x.row0 >> 4;
             const int32_t* e = ext + ((int64_t)a.slot[x.cat] * a.pool.ext_blocks + b0) * 2;
             int lo = 0x7fffffff, hi = -1;
@@ -184,9 +197,10 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(x.rsB, (lptr_t)(Bs + krow * kBStride), 16, lane16, ((k0 + krow) * ldb + x.col0) * 8, 0, 0);
     };
 
-    if (local >= n_tiles) return;
+    int2 e_cur = entry(0);
+    if (e_cur.y == 0) return;
     {
-        const Tile first = decode(local);
+        const Tile first = decode(e_cur);
 #pragma unroll
         for (int q = 0; q < 4; ++q) stage_quarter(first, first.kt0 * kBK, 0, q);
     }
@@ -194,10 +208,11 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
     __syncthreads();                                        // vmcnt(0) + barrier: the first K tile has landed (later
                                                             // ones land behind the barrier that ends each K tile)
 
-    for (int t = local; t < n_tiles; t += n_local_blocks) {
-        const bool has_next = t + n_local_blocks < n_tiles;
-        const Tile cur = decode(t);                         // scalar work, once per output tile; cheaper than carrying it
-        const Tile nxt = decode(has_next ? t + n_local_blocks : t);   // only its A/B descriptors and origins are used (DMA)
+    for (int ti = 0;; ++ti) {
+        const int2 e_nxt = entry(ti + 1);
+        const bool has_next = e_nxt.y != 0;
+        const Tile cur = decode(e_cur);                     // scalar work, once per output tile; cheaper than carrying it
+        const Tile nxt = decode(has_next ? e_nxt : e_cur);  // only its A/B descriptors and origins are used (DMA)
 
         double4_t acc[MI][2];                               // zeroed while the first K tile is in flight
 #pragma unroll
@@ -443,6 +458,8 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
             }
         }
         // the stores need no wait here (they drain during the next main loop)
+        if (!has_next) break;
+        e_cur = e_nxt;
     }
     if (a.stamps && tid == 0) {             // diagnostic build only: per-block placement + lifetime (100 MHz ticks)
         unsigned long long* o = a.stamps + 6 * (size_t)blockIdx.x;
@@ -471,6 +488,17 @@ int prune_gemm_pick_mi(int rows, int n_col_tiles, int n_categories, int slots) {
         if (cost < best_cost * (1.0 - 1e-9)) { best_cost = cost; best = mi; }
     }
     return best;
+}
+
+// Persistent grid: two workgroups per CU (what the register/LDS budget admits), a multiple of 8 so that every XCD gets the
+// same number.  XCD x (blocks x, x+8, ...) owns the (category, column tile) pairs x, x+8, ... and its blocks share those
+// pairs' row tiles: a small launch needs ceil(pairs / 8) * n_row_tiles blocks PER XCD or the owning XCD's few blocks walk
+// the row tiles one after the other while the other XCDs' blocks have nothing to do.
+int prune_gemm_blocks(int n_categories, int n_col_tiles, int n_row_tiles, int n_cu) {
+    int blocks = 2 * n_cu / 8 * 8;
+    const int64_t per_xcd = (((int64_t)n_categories * n_col_tiles + 7) / 8) * n_row_tiles;
+    if (per_xcd * 8 < blocks) blocks = (int)(per_xcd * 8);
+    return blocks;
 }
 
 // ev0 / ev1 (both or neither): start / stop events attached to the dispatch itself (hipExtLaunchKernelGGL) -- the per-launch
@@ -509,20 +537,13 @@ hipError_t launch_prune_gemm(const GemmArgs& a_in, int n_categories, int n_cu, h
     if (a_in.dst_ldt && (a_in.n_leaf || a_in.mode)) return hipErrorInvalidValue;
     GemmArgs a = a_in;
     a.n_categories = n_categories;
-    // persistent grid: two workgroups per CU (what the register/LDS budget admits), a multiple of 8 so that every
-    // XCD gets the same number; fewer when the launch has fewer tiles
     if (n_cu < 8) return hipErrorInvalidValue;
-    int blocks = 2 * n_cu / 8 * 8;
     if (a.mi == 0) {                                       // the caller leaves the tile height to the launcher
-        a.mi = prune_gemm_pick_mi(a.rows, a.n_col_tiles, n_categories, blocks);
+        if (a.plan) return hipErrorInvalidValue;           // (a plan is laid out for one tile height)
+        a.mi = prune_gemm_pick_mi(a.rows, a.n_col_tiles, n_categories, 2 * n_cu / 8 * 8);
         a.n_row_tiles = (a.rows + 16 * a.mi - 1) / (16 * a.mi);
     }
-    // XCD x (blocks x, x+8, ...) owns the (category, column tile) pairs x, x+8, ... and its blocks share those pairs' row
-    // tiles: a small launch needs ceil(pairs / 8) * n_row_tiles blocks PER XCD or the owning XCD's few blocks walk the row
-    // tiles one after the other while the other XCDs' blocks have nothing to do
-    const int64_t per_xcd = (((int64_t)n_categories * a.n_col_tiles + 7) / 8) * a.n_row_tiles;
-    if (per_xcd * 8 < blocks) blocks = (int)(per_xcd * 8);
-    dim3 grid(blocks, 1, 1);
+    dim3 grid(prune_gemm_blocks(n_categories, a.n_col_tiles, a.n_row_tiles, n_cu), 1, 1);
     (void)hipGetLastError();
     switch (a.mi) {
         case 4: launch_mi<4>(a, grid, stream, ev0, ev1); break;

@@ -246,6 +246,10 @@ int cafe_executed_flops(cafe_ctx* ctx, double* flops);
  * NULL); n = cafe_stats.gemm_launches */
 int cafe_debug_launch_flops(cafe_ctx* ctx, double* executed, double* all_k_tiles, int32_t* tile_height, size_t n);
 int cafe_debug_launch_ms(cafe_ctx* ctx, double* ms, size_t n);      /* HIP-event duration of each (profiling on) */
+/* diagnostic / test: reads back the tile lists the planner (extents.hip, tile_plan_kernel) laid out for the K2 launches of the
+ * last call and checks that every tile appears exactly once with the K range its extents give; *n_planned = launches that ran
+ * from a list, *worst_load = largest modelled workgroup load / mean load of its XCD.  CAFE_ERR_STATE on a mismatch. */
+int cafe_debug_plan_check(cafe_ctx* ctx, int32_t* n_planned, double* worst_load);
 int cafe_matrix_size(const cafe_ctx* ctx);
 /* 1: bracket the phases and every K2 launch with HIP events so that cafe_stats.ms_* are measured (bench.py does).
  * 0 (default): no events. */

@@ -667,3 +667,35 @@ def test_assemble_pass_skips_rows_outside_the_extent_without_changing_a_bit(capi
         assert v == v2
         for key in r:
             assert np.array_equal(r[key], r2[key]), key
+
+
+@pytest.mark.gpu
+def test_planned_tile_lists_cover_every_tile_once_and_change_no_bit(capi, oracle, monkeypatch):
+    """With K loops of unequal length the tiles of a K2 launch are dealt to the workgroups by a planner kernel (extents.hip,
+    tile_plan_kernel: per round, longest tile to least-loaded workgroup) instead of in fixed strides.  The lists read back from
+    the device hold every tile of every launch exactly once, with the K range the extents give; results have the bits of a
+    context without the planner (CAFE_NO_PLAN), call after call as the extents change."""
+    pb, _ = synth.make_problem(n_taxa=16, n_families=1500, max_count=250, lam_sim=0.003, seed=11, root_cap=120)
+    assert pb.matrix_size >= 256
+    probs, mult = oracle.discrete_gamma(3, 0.9)
+    prs = [P.Params(lambdas=np.array([l]), prior=P.prior_uniform(pb.max_root_family_size), multipliers=mult, cat_probs=probs)
+           for l in (0.006, 0.0004, 0.0015)]
+    ctx = capi.Context(pb, max_categories=3)
+    got = []
+    for pr in prs:
+        got.append(ctx.score(pr, alpha=0.9, per_family=True))
+        n_planned, worst = ctx.plan_check()
+        assert n_planned == ctx.stats()["gemm_launches"] > 0
+        assert 1.0 <= worst < 3.0
+    v, r = ctx.score(prs[0], per_family=True)                # base model: one category, other lists
+    assert ctx.plan_check()[0] == ctx.stats()["gemm_launches"]
+    monkeypatch.setenv("CAFE_NO_PLAN", "1")
+    plain = capi.Context(pb, max_categories=3)
+    for pr, (v1, r1) in zip(prs, got):
+        v2, r2 = plain.score(pr, alpha=0.9, per_family=True)
+        assert plain.plan_check()[0] == 0
+        assert v1 == v2
+        for key in r1:
+            assert np.array_equal(r1[key], r2[key]), key
+    v2, r2 = plain.score(prs[0], per_family=True)
+    assert v == v2 and all(np.array_equal(r[k], r2[k]) for k in r)
