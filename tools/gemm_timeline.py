@@ -39,3 +39,25 @@ cu = (xcc & 0xF) * 4096 + ((hw >> 8) & 0xF) + 16 * ((hw >> 12) & 1) + 32 * ((hw 
 print("distinct CUs", len(np.unique(cu)), "workgroups per CU", collections.Counter(collections.Counter(cu.tolist()).values()))
 tab = collections.Counter(zip((idx & 7).tolist(), (xcc & 0xF).tolist()))
 print("(blockIdx.x & 7, XCC_ID) -> workgroups:", sorted(tab.items()), "distinct pairs", len(tab))
+x_of = (xcc & 0xF)
+print("finish us by XCD (min / median / max):", [(int(x), round(float(end[x_of == x].min()), 0), round(float(np.median(end[x_of == x])), 0), round(float(end[x_of == x].max()), 0)) for x in np.unique(x_of)])
+se = (hw >> 12) & 1
+print("by shader-engine bit of HW_ID: median finish", [round(float(np.median(end[se == b])), 0) for b in (0, 1)])
+pairs = collections.defaultdict(list)
+for c_, e_ in zip(cu.tolist(), end.tolist()):
+    pairs[c_].append(e_)
+d = np.array([abs(v[0] - v[1]) for v in pairs.values() if len(v) == 2])
+print("two workgroups of a CU finish %.1f us apart on average (all pairs of workgroups: %.1f)" % (d.mean(), np.abs(end[:, None] - end[None, :]).mean()))
+locs = collections.defaultdict(list)
+for c_, i_ in zip(cu.tolist(), idx.tolist()):
+    locs[c_].append(i_ >> 3)
+diffs = collections.Counter(abs(v[0] - v[1]) for v in locs.values() if len(v) == 2)
+print("local index distance of the two workgroups of a CU:", diffs.most_common(5))
+cu_end = np.array([max(v) for v in pairs.values()])
+print("per-CU finish (later of its two workgroups) us: min %.1f p50 %.1f max %.1f; earlier one: p50 %.1f" % (cu_end.min(), np.median(cu_end), cu_end.max(), np.median([min(v) for v in pairs.values()])))
+first_lower = 0
+for c_ in pairs:
+    (e0, e1), (l0, l1) = pairs[c_], locs[c_]
+    if len(pairs[c_]) == 2:
+        first_lower += (e0 < e1) == (l0 < l1)
+print("CUs whose lower-index workgroup finishes first: %d of %d" % (first_lower, len(pairs)))
