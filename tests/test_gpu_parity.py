@@ -699,3 +699,14 @@ def test_planned_tile_lists_cover_every_tile_once_and_change_no_bit(capi, oracle
             assert np.array_equal(r1[key], r2[key]), key
     v2, r2 = plain.score(prs[0], per_family=True)
     assert v == v2 and all(np.array_equal(r[k], r2[k]) for k in r)
+
+
+@pytest.mark.gpu
+def test_random_shapes_with_and_without_the_work_skipping_have_the_same_bits():
+    """tools/fuzz_extents.py: random trees, tables, rates, categories, error models and tile heights, several calls per
+    context -- zero extents, planned tile lists and the assemble pass's row skipping together against CAFE_NO_KSKIP."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_extents.py"), "8", "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "all identical" in r.stdout
