@@ -149,7 +149,9 @@ int build_shard_model(const cafe_problem* p, ShardModel& m) {
 
 // Predicted device time of the shard [a, b), in columns: every interior branch costs one K2 launch and the memory passes
 // of the node's panel, both linear in the node's distinct columns, plus half a column tile of padding and a launch's fixed
-// cost (about 200 columns' worth at the bench shape); the two branches under the root run over one column per family.  A
+// cost (about 200 columns' worth at the bench shape); the two branches under the root run over one column per family, and what
+// else is linear in the families (the assemble passes near the root, K4) adds 5 columns' worth per family (fitted: with 2 the
+// shard of the smallest families, 11 500 of 50 000, ran 1 ms longer than the others outside K2).  A
 // column's weight is 1 up to a largest count of 100 under the node and grows by 2 per M beyond: K2 runs only the K tiles
 // inside matrix extent x panel extent, and the panels of large families have wide extents (measured on eight shards cut by
 // plain column counts: the seven with the small families 27.0-28.9 ms, the one with the largest 32.2 ms).
@@ -165,7 +167,7 @@ double shard_cost(const ShardModel& m, int64_t a, int64_t b) {
         for (int64_t i = a; i < b; ++i) cols += pv[i] < a ? wt[i] : 0.0f;
         cost += cols + 64.0 + 200.0;
     }
-    return cost + 2.0 * (double)(b - a);
+    return cost + 5.0 * (double)(b - a);
 }
 
 int plan_shards(const ShardModel& m, int n_shards, std::vector<int64_t>& bounds) {
