@@ -11,6 +11,11 @@ from cafexp_amd import problem as P, capi, synth
 from cafexp_amd.gamma_rates import discrete_gamma
 
 pb, _ = synth.make_problem(n_families=50000)
+if len(sys.argv) > 1:                                   # R/W: one shard of the library's plan
+    import dataclasses
+    r_, w_ = (int(x) for x in sys.argv[1].split("/"))
+    mine = capi.shard_plan(pb, w_, 8)[r_]
+    pb = dataclasses.replace(pb, counts=np.ascontiguousarray(pb.counts[mine]), family_ids=[pb.family_ids[i] for i in mine])
 probs, mult = discrete_gamma(8, 2.0)
 pr = P.Params(lambdas=np.array([0.002]), prior=P.prior_uniform(750), multipliers=mult, cat_probs=probs)
 ctx = capi.Context(pb, max_categories=8)
