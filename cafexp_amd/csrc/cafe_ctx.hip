@@ -664,6 +664,7 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     // tile lists for the K2 launches: room for the tallest list any tile height can ask for
     c->use_plan = c->kpool.ext && c->stats.n_chunks == 1 && !std::getenv("CAFE_NO_PLAN");
     if (const char* e = std::getenv("CAFE_PLAN_FIXED")) c->plan_fixed = std::max(0, atoi(e));
+    if (const char* e = std::getenv("CAFE_PLAN_BIAS")) c->plan_bias = std::min(50, std::max(0, atoi(e)));
     if (c->use_plan) {
         size_t entries = 0, n_gemm = 0;
         for (const Op& op : c->ops) {
@@ -883,7 +884,7 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
             d.bext = c->panel_extents ? c->d_tileext[op.child] : nullptr;
             d.mi = mi; d.n_row_tiles = nrt; d.n_col_tiles = nct; d.n_categories = K; d.k_valid = c->M + 1;
             d.blocks_per_xcd = nlb; d.rounds = rounds; d.plan = c->d_plan + used;
-            d.fixed = c->plan_fixed;
+            d.fixed = c->plan_fixed; d.bias = c->plan_bias;
             op_plan[i] = d.plan; op_rounds[i] = rounds;
             used += need;
             ++n_desc;

@@ -109,6 +109,7 @@ struct PlanLaunch {
     int32_t blocks_per_xcd;         // workgroups of the launch / 8
     int32_t rounds;                 // list length per workgroup
     int32_t fixed;                  // what an output tile costs beyond its K loop, in K tiles
+    int32_t bias;                   // percent: the first-dispatched workgroup of a CU (local index < 32 of 64) runs that much faster
     int2* plan;                     // [8][blocks_per_xcd][rounds]
 };
 hipError_t launch_tile_plan(const PlanLaunch* d_launches, int n_launches, hipStream_t stream);

@@ -74,7 +74,10 @@ hipError_t launch_node_extents(const ExtArgs& a, int max_col_tiles, int n_catego
 }
 
 // Tile lists of the K2 launches of a call (PlanLaunch, cafe_kernels.h): one wave per (XCD, launch), lane = workgroup.
-// Cost of a tile = its K tiles + PlanLaunch::fixed.
+// Cost of a tile = its K tiles + PlanLaunch::fixed.  With the full grid (64 workgroups per XCD) workgroups j and j + 32 share
+// a CU, and the one dispatched first (j < 32) wins the MFMA arbitration: given equal lists it ALWAYS finishes first, 8 % of
+// the launch earlier, and the CU runs one workgroup to the end (tools/gemm_timeline.py).  The planner therefore charges a
+// tile `bias` percent less to j < 32 and as much more to j >= 32, so that the favoured workgroup takes more of the work.
 __global__ __launch_bounds__(64) void tile_plan_kernel(const PlanLaunch* __restrict__ launches) {
     const PlanLaunch& L = launches[blockIdx.y];
     const int xcd = blockIdx.x, lane = threadIdx.x;
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(64) void tile_plan_kernel(const PlanLaunch* __restr
         if (lane < nlb) {
             const int w = s_who[crank];
             L.plan[((int64_t)xcd * nlb + w) * L.rounds + r] = valid ? make_int2(t, (kt0 << 16) | nkt) : make_int2(0, 0);
-            if (valid) s_load[w] += cst;
+            if (valid) s_load[w] += cst * ((nlb == 64 && L.bias) ? (w < 32 ? 100 - L.bias : 100 + L.bias) : 100);
         }
         __syncthreads();
     }
