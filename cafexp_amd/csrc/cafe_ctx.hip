@@ -678,7 +678,7 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
                 const int nlb = prune_gemm_blocks(c->Kmax, nct, nrt, c->n_cu) / 8;
                 const int64_t tiles = (((int64_t)c->Kmax * nct + 7) / 8) * nrt;
                 (void)nlb;
-                worst = std::max(worst, (size_t)8 * (size_t)(tiles + 64));      // >= 8 * nlb * ceil(tiles / nlb) for any K <= Kmax
+                worst = std::max(worst, (size_t)8 * (size_t)(tiles + 64 * (1 + kPlanSlack)));   // >= 8 * nlb * (ceil(tiles / nlb) + slack), any K <= Kmax
             }
             entries += worst;
         }
@@ -874,7 +874,7 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
             const int nrt = (rows + 16 * mi - 1) / (16 * mi);
             const int nlb = prune_gemm_blocks(K, nct, nrt, c->n_cu) / 8;
             const int64_t tiles = (((int64_t)K * nct + 7) / 8) * nrt;
-            const int rounds = (int)((tiles + nlb - 1) / nlb);
+            const int rounds = (int)((tiles + nlb - 1) / nlb) + kPlanSlack;
             const size_t need = (size_t)8 * nlb * rounds;
             if (used + need > c->plan_entries) continue;    // (cannot happen: the room was sized for the tallest list)
             PlanLaunch& d = c->h_plan_desc[n_desc];

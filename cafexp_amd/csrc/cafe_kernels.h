@@ -112,6 +112,7 @@ struct PlanLaunch {
     int32_t bias;                   // percent: the first-dispatched workgroup of a CU (local index < 32 of 64) runs that much faster
     int2* plan;                     // [8][blocks_per_xcd][rounds]
 };
+constexpr int kPlanSlack = 2;       // spare list entries per workgroup (the planner's last rounds are dealt as one batch)
 hipError_t launch_tile_plan(const PlanLaunch* d_launches, int n_launches, hipStream_t stream);
 // workgroups of a K2 launch (a multiple of 8): two per CU, fewer when the launch has fewer tiles
 int prune_gemm_blocks(int n_categories, int n_col_tiles, int n_row_tiles, int n_cu);

@@ -73,45 +73,55 @@ hipError_t launch_node_extents(const ExtArgs& a, int max_col_tiles, int n_catego
     return hipGetLastError();
 }
 
+constexpr int kPlanTail = 3;
 // Tile lists of the K2 launches of a call (PlanLaunch, cafe_kernels.h): one wave per (XCD, launch), lane = workgroup.
 // Cost of a tile = its K tiles + PlanLaunch::fixed.  With the full grid (64 workgroups per XCD) workgroups j and j + 32 share
 // a CU, and the one dispatched first (j < 32) wins the MFMA arbitration: given equal lists it ALWAYS finishes first, 8 % of
 // the launch earlier, and the CU runs one workgroup to the end (tools/gemm_timeline.py).  The planner therefore charges a
 // tile `bias` percent less to j < 32 and as much more to j >= 32, so that the favoured workgroup takes more of the work.
+// K range of tile t of XCD `xcd`'s list (the same arithmetic as the kernel's own decode, prune_gemm.hip)
+__device__ inline void plan_tile_range(const PlanLaunch& L, int xcd, int t, int& kt0, int& nkt) {
+    const int row_tile = t % L.n_row_tiles;
+    const int pair = xcd + 8 * (t / L.n_row_tiles);
+    const int ct = pair % L.n_col_tiles, cat = pair / L.n_col_tiles;
+    const int b0 = row_tile * L.mi;
+    const int32_t* e = L.aext + ((int64_t)L.slot[cat] * L.ext_blocks + b0) * 2;
+    int lo = 0x7fffffff, hi = -1;
+    for (int b = 0; b < L.mi; ++b)
+        if (b0 + b < L.ext_blocks) { lo = min(lo, e[2 * b]); hi = max(hi, e[2 * b + 1]); }
+    int zlo = 0;
+    if (L.bext) {
+        const int32_t* be = L.bext + ((int64_t)cat * L.n_col_tiles + ct) * 2;
+        lo = max(lo, be[0]);
+        hi = min(hi, be[1]);
+        if (be[1] >= be[0]) zlo = be[0];
+    }
+    if (hi < lo) { lo = zlo; hi = zlo; }
+    hi = min(hi, L.k_valid - 1);
+    kt0 = lo / kBK;
+    nkt = hi / kBK - lo / kBK + 1;
+}
+
+// The last kPlanTail rounds are dealt as ONE batch, longest tile first, each to the workgroup with the least load at that
+// moment (a workgroup may then end up with a tile more or less than its neighbours: lists have kPlanSlack spare entries).
 __global__ __launch_bounds__(64) void tile_plan_kernel(const PlanLaunch* __restrict__ launches) {
     const PlanLaunch& L = launches[blockIdx.y];
     const int xcd = blockIdx.x, lane = threadIdx.x;
     const int nlb = L.blocks_per_xcd;
     const int my_pairs = (L.n_categories * L.n_col_tiles - xcd + 7) >> 3;
     const int n_tiles = my_pairs * L.n_row_tiles;
+    const int weight = (nlb == 64 && L.bias) ? (lane < 32 ? 100 - L.bias : 100 + L.bias) : 100;   // of this lane's workgroup
     __shared__ int s_load[64], s_cost[64], s_who[64];
+    __shared__ int t_cost[kPlanTail * 64], t_y[kPlanTail * 64], t_by_rank[kPlanTail * 64];
     s_load[lane] = 0;
     __syncthreads();
-    for (int r = 0; r < L.rounds; ++r) {
+    const int head = max(0, (n_tiles + nlb - 1) / nlb - kPlanTail);      // full rounds dealt one by one
+    int2* __restrict__ mylist = L.plan + ((int64_t)xcd * nlb + lane) * L.rounds;   // (lanes < nlb)
+    for (int r = 0; r < head; ++r) {
         const int t = r * nlb + lane;
-        const bool valid = lane < nlb && t < n_tiles;
+        const bool valid = lane < nlb;
         int kt0 = 0, nkt = 0;
-        if (valid) {                                       // (the same arithmetic as the kernel's own decode, prune_gemm.hip)
-            const int row_tile = t % L.n_row_tiles;
-            const int pair = xcd + 8 * (t / L.n_row_tiles);
-            const int ct = pair % L.n_col_tiles, cat = pair / L.n_col_tiles;
-            const int b0 = row_tile * L.mi;
-            const int32_t* e = L.aext + ((int64_t)L.slot[cat] * L.ext_blocks + b0) * 2;
-            int lo = 0x7fffffff, hi = -1;
-            for (int b = 0; b < L.mi; ++b)
-                if (b0 + b < L.ext_blocks) { lo = min(lo, e[2 * b]); hi = max(hi, e[2 * b + 1]); }
-            int zlo = 0;
-            if (L.bext) {
-                const int32_t* be = L.bext + ((int64_t)cat * L.n_col_tiles + ct) * 2;
-                lo = max(lo, be[0]);
-                hi = min(hi, be[1]);
-                if (be[1] >= be[0]) zlo = be[0];
-            }
-            if (hi < lo) { lo = zlo; hi = zlo; }
-            hi = min(hi, L.k_valid - 1);
-            kt0 = lo / kBK;
-            nkt = hi / kBK - lo / kBK + 1;
-        }
+        if (valid) plan_tile_range(L, xcd, t, kt0, nkt);
         const int cst = valid ? nkt + L.fixed : -1;
         const int mine = s_load[lane];
         s_cost[lane] = cst;
@@ -122,15 +132,45 @@ __global__ __launch_bounds__(64) void tile_plan_kernel(const PlanLaunch* __restr
             crank += (ck > cst || (ck == cst && k < lane)) ? 1 : 0;
             lrank += (lk < mine || (lk == mine && k < lane)) ? 1 : 0;
         }
-        if (lane < nlb) s_who[lrank] = lane;
+        if (valid) s_who[lrank] = lane;
         __syncthreads();
-        if (lane < nlb) {
+        if (valid) {
             const int w = s_who[crank];
-            L.plan[((int64_t)xcd * nlb + w) * L.rounds + r] = valid ? make_int2(t, (kt0 << 16) | nkt) : make_int2(0, 0);
-            if (valid) s_load[w] += cst * ((nlb == 64 && L.bias) ? (w < 32 ? 100 - L.bias : 100 + L.bias) : 100);
+            L.plan[((int64_t)xcd * nlb + w) * L.rounds + r] = make_int2(t, (kt0 << 16) | nkt);
+            const int ww = (nlb == 64 && L.bias) ? (w < 32 ? 100 - L.bias : 100 + L.bias) : 100;
+            s_load[w] += cst * ww;
         }
         __syncthreads();
     }
+    // ---- the rest as one batch
+    const int t0 = head * nlb, n_tail = n_tiles - t0;
+    for (int i = lane; i < n_tail; i += 64) {
+        int kt0, nkt;
+        plan_tile_range(L, xcd, t0 + i, kt0, nkt);
+        t_cost[i] = nkt + L.fixed;
+        t_y[i] = (kt0 << 16) | nkt;
+    }
+    __syncthreads();
+    for (int i = lane; i < n_tail; i += 64) {
+        const int c = t_cost[i];
+        int rank = 0;
+        for (int j = 0; j < n_tail; ++j) rank += (t_cost[j] > c || (t_cost[j] == c && j < i)) ? 1 : 0;
+        t_by_rank[rank] = i;
+    }
+    __syncthreads();
+    int pos = head;
+    unsigned load = (unsigned)s_load[lane];
+    for (int q = 0; q < n_tail; ++q) {
+        const int item = t_by_rank[q];
+        unsigned key = (lane < nlb && pos < L.rounds) ? ((min(load, 0x01FFFFFFu) << 6) | (unsigned)lane) : 0xFFFFFFFFu;
+        for (int off = 32; off > 0; off >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, off));
+        if (key != 0xFFFFFFFFu && lane == (int)(key & 63u)) {
+            mylist[pos++] = make_int2(t0 + item, t_y[item]);
+            load += (unsigned)(t_cost[item] * weight);
+        }
+    }
+    if (lane < nlb)
+        for (; pos < L.rounds; ++pos) mylist[pos] = make_int2(0, 0);
 }
 
 hipError_t launch_tile_plan(const PlanLaunch* d_launches, int n_launches, hipStream_t stream) {
