@@ -149,6 +149,7 @@ struct cafe_ctx {
     // tile lists of the K2 launches (tile_plan_kernel): one descriptor per launch, rebuilt per call (the tile heights may
     // change), uploaded when it differs from the last upload
     bool use_plan = false;
+    int plan_launches_last = 0;              // K2 launches of the last recorded call that ran from planned lists
     int plan_bias = 8;                       // percent by which the first-dispatched workgroup of a CU outruns the other (measured; CAFE_PLAN_BIAS)
     int plan_fixed = 4;                      // cost of an output tile beyond its K loop, in K tiles (fitted: DESIGN.md; CAFE_PLAN_FIXED)
     int2* d_plan = nullptr;

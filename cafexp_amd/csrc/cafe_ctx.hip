@@ -898,6 +898,7 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
             }
             HIP_TRY(c, launch_tile_plan(c->d_plan_desc, n_desc, s));
         }
+        c->plan_launches_last = n_desc;
     }
 
     // ---- prune, chunk by chunk
@@ -1417,7 +1418,7 @@ int cafe_debug_plan_check(cafe_ctx* ctx, int32_t* n_planned, double* worst_load)
     if (!ctx) return CAFE_ERR_ARGUMENT;
     if (n_planned) *n_planned = 0;
     if (worst_load) *worst_load = 1.0;
-    if (!ctx->use_plan || ctx->plan_desc_sent.empty()) return CAFE_OK;
+    if (!ctx->use_plan || ctx->plan_launches_last == 0 || ctx->plan_desc_sent.empty()) return CAFE_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
     const int nb = ctx->kpool.ext_blocks;
