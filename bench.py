@@ -237,6 +237,7 @@ def main():
     from cafexp_amd.gamma_rates import discrete_gamma
 
     native_comm = world > 1 and args.backend == "nccl"
+    lib_reduce = native_comm                          # the all-reduce is issued inside cafe_score (cafe_comm_attach)
     device = local_rank % max(1, torch.cuda.device_count()) if native_comm or world == 1 else 0
     torch.cuda.set_device(device)
     if world > 1:
@@ -280,7 +281,21 @@ def main():
             if rank == 0:
                 idt.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
             dist.broadcast(idt, 0)
-            ctx.comm_attach(bytes(idt.cpu().numpy().tobytes()), world, rank)
+            ok = torch.ones(1, dtype=torch.int32, device="cuda")
+            try:
+                ctx.comm_attach(bytes(idt.cpu().numpy().tobytes()), world, rank)
+            except capi.CafeError as e:                # every rank must take the same path: agree on it
+                print("rank %d: cafe_comm_attach failed (%s)" % (rank, e), file=sys.stderr, flush=True)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                # the library's communicator could not be set up: the pair is reduced by torch.distributed instead (the same
+                # RCCL all-reduce of two doubles, issued from here rather than from inside cafe_score)
+                try:
+                    ctx.comm_detach()
+                except capi.CafeError:
+                    pass
+                lib_reduce = False
 
     buf = torch.zeros(2, dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream()
@@ -288,10 +303,13 @@ def main():
     def step():
         if sharded is not None:
             return sharded.score(pr, alpha=args.alpha)
-        if world == 1 or native_comm:
+        if world == 1 or lib_reduce:
             return ctx.score(pr, alpha=args.alpha)    # N > 1: ends with the library's ncclAllReduce of {sum lnL, rejects}
-        ctx.score_partial(pr, buf.data_ptr(), stream.cuda_stream, alpha=args.alpha)       # gloo rehearsal
-        pair = buf.cpu()
+        ctx.score_partial(pr, buf.data_ptr(), stream.cuda_stream, alpha=args.alpha)
+        if native_comm:                               # (only if cafe_comm_attach failed) RCCL all-reduce issued by torch
+            dist.all_reduce(buf)
+            return ctx.finish(buf.cpu().numpy())
+        pair = buf.cpu()                              # gloo rehearsal
         dist.all_reduce(pair)
         return ctx.finish(pair.numpy())
 
@@ -367,8 +385,10 @@ def main():
             "config": {"workload": "synthetic %d families / %d taxa / max family size %d (matrix order %d), gamma K=%d, lambda=%g alpha=%g, "
                                    "family-sharded over %d GPU(s)" % (F, args.taxa, args.max_count, pb.matrix_size, K, args.lam, args.alpha, n_gpus),
                        "families": F, "taxa": args.taxa, "max_family_size": args.max_count, "gamma_categories": K,
-                       "parallelism": "family-shard x%d + 1 RCCL all-reduce inside cafe_score (%s)"
-                                      % (n_gpus, "one process, a host thread per GPU" if sharded is not None else "one process per GPU")},
+                       "parallelism": "family-shard x%d + 1 RCCL all-reduce %s (%s)"
+                                      % (n_gpus, "inside cafe_score" if (lib_reduce or sharded is not None or world == 1) else
+                                         "issued by torch.distributed (cafe_comm_attach failed)" if native_comm else "on the host (gloo rehearsal)",
+                                         "one process, a host thread per GPU" if sharded is not None else "one process per GPU")},
             "neg_lnl": value,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
@@ -411,7 +431,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
-        if native_comm:
+        if lib_reduce:
             ctx.comm_detach()
         dist.destroy_process_group()
     if sharded is not None:
