@@ -427,6 +427,20 @@ def main():
                                                 "prune_gemm_tflops": plain.executed_flops() / (ps["ms_gemm"] * 1e-3) / 1e12 if ps["ms_gemm"] > 0 else None,
                                                 "identical_to_headline": v == value}
                 plain.close()
+                # and with every K tile of every column run (CAFE_NO_KSKIP, read at cafe_create: no zero extents, no planned
+                # tile lists): what the call costs when the matrices have no exact zeros to skip (large lambda * t)
+                os.environ["CAFE_NO_KSKIP"] = "1"
+                try:
+                    dense = capi.Context(pb, max_categories=max(1, K), device=device)
+                finally:
+                    del os.environ["CAFE_NO_KSKIP"]
+                dense.set_profiling(True)
+                sec, v = timed_calls(lambda: dense.score(pr, alpha=args.alpha), 2)
+                ds = dense.stats()
+                out["every_k_tile"] = {"ms_per_step": 1e3 * sec, "value": F / sec, "neg_lnl": v,
+                                       "prune_gemm_tflops": ds["gemm_flops"] / (ds["ms_gemm"] * 1e-3) / 1e12 if ds["ms_gemm"] > 0 else None,
+                                       "identical_to_headline": v == value}
+                dense.close()
                 out["other_configs"] = other_configs(args)
         print(json.dumps(out), flush=True)
     if world > 1:
