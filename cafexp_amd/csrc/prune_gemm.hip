@@ -64,7 +64,6 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
     constexpr int SA = a_stride(BM);
     constexpr int A_TILE = kBK * SA, B_TILE = kBK * kBStride, STAGE = A_TILE + B_TILE;
     __shared__ double lds[2 * STAGE];
-    typedef int int4_t __attribute__((ext_vector_type(4)));
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
