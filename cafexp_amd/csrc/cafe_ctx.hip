@@ -662,7 +662,8 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
 
 
     // tile lists for the K2 launches: room for the tallest list any tile height can ask for
-    c->use_plan = c->kpool.ext && c->stats.n_chunks == 1 && !std::getenv("CAFE_NO_PLAN");
+    // (the planner is one 64-lane wave per XCD, a lane per workgroup: MI355X has 32 CUs x 2 workgroups per XCD)
+    c->use_plan = c->kpool.ext && c->stats.n_chunks == 1 && 2 * c->n_cu / 8 <= 64 && !std::getenv("CAFE_NO_PLAN");
     if (const char* e = std::getenv("CAFE_PLAN_FIXED")) c->plan_fixed = std::max(0, atoi(e));
     if (const char* e = std::getenv("CAFE_PLAN_BIAS")) c->plan_bias = std::min(50, std::max(0, atoi(e)));
     if (c->use_plan) {
