@@ -33,6 +33,7 @@ struct Op {
     bool has_gath;
     int gath_child;
     int gath_panel;
+    int stream;                 // 0, or 1: the op belongs to the subtree that may run on the second stream (CAFE_STREAMS=2)
 };
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -148,6 +149,12 @@ struct cafe_ctx {
     int32_t* h_ext = nullptr;                // pinned [max_kslots][ext_blocks][2]
     // tile lists of the K2 launches (tile_plan_kernel): one descriptor per launch, rebuilt per call (the tile heights may
     // change), uploaded when it differs from the last upload
+    // experimental (CAFE_STREAMS=2 at cafe_create): the second interior subtree under the root gets its own panels and runs on
+    // a second stream, forked behind K1 / extents / planner and joined in front of the root's launches
+    int n_streams = 1;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    void* side_alloc = nullptr;              // PanelAlloc of the side subtree while the schedule is emitted
     bool use_plan = false;
     int plan_launches_last = 0;              // K2 launches of the last recorded call that ran from planned lists
     int plan_bias = 8;                       // percent by which the first-dispatched workgroup of a CU outruns the other (measured; CAFE_PLAN_BIAS)

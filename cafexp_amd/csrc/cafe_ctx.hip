@@ -65,13 +65,33 @@ struct PanelAlloc {
     void put(int p) { free_list.push_back(p); }
 };
 
+constexpr int kSideBase = 1 << 20;
 int emit_node(cafe_ctx* c, int v, const std::vector<int>& need, PanelAlloc& pa) {
     std::vector<int> inner, leaves;
     for (int u : c->children[v]) (c->leaf_taxon[u] < 0 ? inner : leaves).push_back(u);
     std::vector<int> order = inner;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return need[x] > need[y]; });
     std::map<int, int> panel_of;
-    for (int u : order) panel_of[u] = emit_node(c, u, need, pa);
+    for (size_t idx = 0; idx < order.size(); ++idx) {
+        const int u = order[idx];
+        if (v == c->root && c->side_alloc && order.size() >= 2 && idx == 1) {
+            // the root's second interior subtree: panels of its own (ids from kSideBase, renumbered behind the main pool
+            // once that is complete), every launch tagged for the second stream
+            const size_t first = c->ops.size();
+            const int p = emit_node(c, u, need, *static_cast<PanelAlloc*>(c->side_alloc));
+            for (size_t i = first; i < c->ops.size(); ++i) {
+                Op& o = c->ops[i];
+                o.stream = 1;
+                o.dst_panel += kSideBase;
+                if (o.type == 1) o.src_panel += kSideBase;
+                for (int j = 0; j < o.n_src; ++j) o.src_panels[j] += kSideBase;
+                if (o.has_gath) o.gath_panel += kSideBase;
+            }
+            panel_of[u] = p + kSideBase;
+        } else {
+            panel_of[u] = emit_node(c, u, need, pa);
+        }
+    }
     const int dst = pa.get();
     bool init = false;
     // A parent with interior children folds (up to kMaxLeafPerOp of) its leaf children into the epilogue of
@@ -315,6 +335,9 @@ void free_device(cafe_ctx* c) {
     if (c->ev_upload) hipEventDestroy(c->ev_upload);
     for (auto& e : c->ev) if (e) hipEventDestroy(e);
     for (auto& e : c->gemm_ev) hipEventDestroy(e);
+    if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->stream) hipStreamDestroy(c->stream);
 }
 
@@ -420,6 +443,9 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     HIP_TRY(c, hipSetDevice(c->device));
     c->device_ready = true;
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
 
     // counts, taxon-major, padded families replicate an all-zero family
     {
@@ -439,10 +465,20 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     if (c->subtree_dedup) { const int rc = compute_patterns(c, p, uniq); if (rc != CAFE_OK) return rc; }
     std::vector<int> need(c->n_nodes, 0);
     panel_need(c, c->root, need);
+    if (const char* e = std::getenv("CAFE_STREAMS")) c->n_streams = atoi(e) == 2 ? 2 : 1;
     {
-        PanelAlloc pa;
+        PanelAlloc pa, side;
+        c->side_alloc = c->n_streams == 2 ? &side : nullptr;
         c->root_panel = emit_node(c, c->root, need, pa);
-        c->n_panels = pa.high;
+        c->side_alloc = nullptr;
+        auto fix = [&](int& id) { if (id >= kSideBase) id = pa.high + (id - kSideBase); };
+        for (Op& o : c->ops) {
+            fix(o.dst_panel);
+            if (o.type == 1) fix(o.src_panel);
+            for (int j = 0; j < o.n_src; ++j) fix(o.src_panels[j]);
+            if (o.has_gath) fix(o.gath_panel);
+        }
+        c->n_panels = pa.high + side.high;
     }
 
     // matrix pools: one slot per (distinct quantized branch length, lambda index) pair and category, per layout.
@@ -584,6 +620,7 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
         c->subtree_dedup = false;
         c->panel_extents = false;
         c->ops.clear();
+        c->n_streams = 1;
         PanelAlloc pa;
         c->root_panel = emit_node(c, c->root, need, pa);
         c->n_panels = pa.high;
@@ -902,6 +939,36 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
         c->plan_launches_last = n_desc;
     }
 
+    // ---- launch order.  Two streams (experimental): the side subtree's launches are enqueued alternately with the main one's
+    // so that both streams have work from the start; the root's launches come last, behind the join.
+    const bool two_streams = c->n_streams == 2 && !capturing && c->stream2;
+    std::vector<size_t> launch_order;
+    {
+        std::vector<size_t> q[2], tail;
+        for (size_t i = 0; i < c->ops.size(); ++i) {
+            const Op& op = c->ops[i];
+            if (two_streams && op.parent == c->root) tail.push_back(i);
+            else q[two_streams ? op.stream : 0].push_back(i);
+        }
+        size_t a = 0, b = 0;
+        while (a < q[0].size() || b < q[1].size()) {      // proportional merge
+            if (b >= q[1].size() || (a < q[0].size() && a * q[1].size() <= b * q[0].size())) launch_order.push_back(q[0][a++]);
+            else launch_order.push_back(q[1][b++]);
+        }
+        launch_order.insert(launch_order.end(), tail.begin(), tail.end());
+    }
+    bool forked = false;
+    if (two_streams) {
+        bool any_side = false;
+        for (const Op& op : c->ops) any_side = any_side || op.stream == 1;
+        if (any_side) {
+            HIP_TRY(c, hipEventRecord(c->ev_fork, s));      // behind K1, the extent kernels and the planner
+            HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            forked = true;
+        }
+    }
+    bool joined = false;
+
     // ---- prune, chunk by chunk
     c->gemm_ev_used = 0;
     c->gemm_launches_info.clear();
@@ -909,7 +976,14 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
         const int64_t cols = std::min<int64_t>(c->chunk_cols, c->Fp - f0);
         // columns (and leading dimension) of a node's panel: one per distinct leaf-count pattern under it, or the chunk
         auto cols_of = [&](int v) -> int64_t { return c->subtree_dedup ? c->pat_cols[v] : cols; };
-        for (const Op& op : c->ops) {
+        for (const size_t op_index : launch_order) {
+            const Op& op = c->ops[op_index];
+            hipStream_t ls = (forked && op.stream == 1 && op.parent != c->root) ? c->stream2 : s;      // this op's stream
+            if (forked && !joined && op.parent == c->root) {
+                HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
+                HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
+                joined = true;
+            }
             const int rows = op.to_root ? c->R : c->M + 1;
             const int rows_store = op.to_root ? c->R : c->kc;
             double* dst = c->d_panels + (int64_t)op.dst_panel * c->panel_stride;
@@ -938,7 +1012,7 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
                 }
                 // (the root's vector is read whole by the reduction and has no extent record)
                 g.tileext = c->panel_extents && op.n_src > 0 && !op.to_root && !c->no_asm_skip ? c->d_tileext[op.parent] : nullptr;
-                HIP_TRY(c, launch_leaf_gather(g, K, s));
+                HIP_TRY(c, launch_leaf_gather(g, K, ls));
             } else {
                 GemmArgs g{};
                 g.pool = c->kpool;
@@ -971,10 +1045,10 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
                     g.gath_map = c->d_edge_map[op.gath_child];
                 }
                 if (events && c->gemm_ev_used + 2 <= c->gemm_ev.size()) {       // start / stop events ride on the dispatch itself
-                    HIP_TRY(c, launch_prune_gemm(g, K, c->n_cu, s, c->gemm_ev[c->gemm_ev_used], c->gemm_ev[c->gemm_ev_used + 1]));
+                    HIP_TRY(c, launch_prune_gemm(g, K, c->n_cu, ls, c->gemm_ev[c->gemm_ev_used], c->gemm_ev[c->gemm_ev_used + 1]));
                     c->gemm_ev_used += 2;
                 } else {
-                    HIP_TRY(c, launch_prune_gemm(g, K, c->n_cu, s));
+                    HIP_TRY(c, launch_prune_gemm(g, K, c->n_cu, ls));
                 }
                 c->stats.gemm_launches += 1;
                 c->gemm_launches_info.push_back({op.child, g.rows, gc, K, g.mi});
@@ -983,6 +1057,11 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
                 c->stats.gemm_flops_per_family += 2.0 * rows * (c->M + 1) * (double)cols * K;
                 c->stats.gemm_bytes += 8.0 * K * ((double)rows * (c->M + 1) + (double)(c->M + 1) * gc + (double)rows * gc);
             }
+        }
+        if (forked && !joined) {                           // (no launch of the root's came by: cannot happen, the root has ops)
+            HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
+            HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
+            joined = true;
         }
         if (events && f0 + c->chunk_cols >= c->Fp) HIP_TRY(c, hipEventRecord(c->ev[2], s));
         ReduceArgs r{};

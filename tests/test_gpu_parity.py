@@ -710,3 +710,31 @@ def test_random_shapes_with_and_without_the_work_skipping_have_the_same_bits():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_extents.py"), "8", "3"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "all identical" in r.stdout
+
+
+@pytest.mark.gpu
+def test_second_stream_for_the_roots_other_subtree_changes_no_bit(capi, oracle, monkeypatch):
+    """CAFE_STREAMS=2 (experimental, read at cafe_create): the root's second interior subtree gets panels of its own and
+    runs on a second stream, forked behind K1 / extents / planner and joined in front of the root's launches.  Same bits
+    as the one-stream schedule, call after call, base and gamma, with and without an error model."""
+    for n_dev in (0, 3):
+        pb, _ = synth.make_problem(n_taxa=24, n_families=1200, max_count=260, lam_sim=0.003, seed=23, root_cap=120, n_deviations=n_dev)
+        em = None
+        if n_dev:
+            em = P.error_model_table(P.default_error_model(pb.max_family_size)[:1] + [[0.05, 0.9, 0.05]], pb.max_family_size)
+        probs, mult = oracle.discrete_gamma(4, 0.8)
+        prs = [(P.Params(lambdas=np.array([l]), prior=P.prior_uniform(pb.max_root_family_size), multipliers=mult, cat_probs=probs, error_model=em), 0.8)
+               for l in (0.004, 0.0007)]
+        prs.append((P.Params(lambdas=np.array([0.002]), prior=P.prior_uniform(pb.max_root_family_size), error_model=em), 1.0))
+        one = capi.Context(pb, max_categories=4)
+        monkeypatch.setenv("CAFE_STREAMS", "2")
+        two = capi.Context(pb, max_categories=4)
+        monkeypatch.delenv("CAFE_STREAMS")
+        assert two.stats()["panel_bytes"] > one.stats()["panel_bytes"]          # (the side subtree's own panels)
+        for _ in range(2):
+            for pr, alpha in prs:
+                v1, r1 = one.score(pr, alpha=alpha, per_family=True)
+                v2, r2 = two.score(pr, alpha=alpha, per_family=True)
+                assert v1 == v2
+                for key in r1:
+                    assert np.array_equal(r1[key], r2[key]), key
