@@ -441,6 +441,20 @@ def main():
                                        "prune_gemm_tflops": ds["gemm_flops"] / (ds["ms_gemm"] * 1e-3) / 1e12 if ds["ms_gemm"] > 0 else None,
                                        "identical_to_headline": v == value}
                 dense.close()
+                # experimental, off by default: the root's second subtree on a second stream; no
+                # per-launch events (overlapping launches make them meaningless), so against the same call without events
+                two = {}
+                for n_streams in ("1", "2"):
+                    os.environ["CAFE_STREAMS"] = n_streams
+                    try:
+                        cs = capi.Context(pb, max_categories=max(1, K), device=device)
+                    finally:
+                        del os.environ["CAFE_STREAMS"]
+                    sec, v = timed_calls(lambda: cs.score(pr, alpha=args.alpha), 3)
+                    two[n_streams] = (sec, v)
+                    cs.close()
+                out["two_streams_experimental"] = {"ms_per_step": 1e3 * two["2"][0], "one_stream_no_events_ms_per_step": 1e3 * two["1"][0],
+                                                   "identical_to_headline": two["2"][1] == value and two["1"][1] == value}
                 out["other_configs"] = other_configs(args)
         print(json.dumps(out), flush=True)
     if world > 1:
