@@ -56,6 +56,10 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip one_column_per_family and other_configs (N = 1 only)")
     ap.add_argument("--single-process", action="store_true", help="N > 1: one process drives all GPUs (cafe_create_sharded)")
     ap.add_argument("--emulate-shard", default="", help="R/W: rehearsal on one GPU of what rank R of W would run (no collective)")
+    ap.add_argument("--shard-times", default="", help="with --emulate-shard: ms per shard measured under the default plan (comma list): "
+                    "use the plan rebalanced by them, as the ranks of an N > 1 run do after their first calls")
+    ap.add_argument("--rebalance", action="store_true", help="N > 1: one step of measured rebalancing during set-up (every rank times a few "
+                    "calls of its predicted shard, the plan is corrected by the gathered times); rehearsed: largest shard 3.5 %% -> 3.1 %% above the mean")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI, issued by the library (the real thing); gloo: rehearsal of the N>1 path on a box "
                          "with fewer GPUs than ranks (all ranks share GPU 0, the pair is summed on the host)")
@@ -257,6 +261,7 @@ def main():
         pr = P.Params(lambdas=np.array([args.lam]), prior=P.prior_uniform(pb.max_root_family_size))
 
     sharded = None
+    plan_note = None
     if args.single_process and n_gpus > 1:
         sharded = capi.Sharded(pb, list(range(n_gpus)), max_categories=max(1, K))
         ctx = sharded.shard(0)
@@ -264,15 +269,40 @@ def main():
             sharded.shard(r).set_profiling(r == 0)
     else:
         # every rank derives the same plan; shards are balanced by predicted device time (distinct subtree patterns)
+        def shard_of(fam):
+            return dataclasses.replace(pb, counts=np.ascontiguousarray(pb.counts[fam]), family_ids=[pb.family_ids[i] for i in fam])
+
         if args.emulate_shard:
             er, ew = (int(x) for x in args.emulate_shard.split("/"))
-            mine = capi.shard_plan(pb, ew, max(1, K))[er]
+            plan = capi.shard_plan(pb, ew, max(1, K))
+            if args.shard_times:
+                plan = capi.rebalanced_plan(pb, plan, [float(x) for x in args.shard_times.split(",")], max(1, K))
+                plan_note = "rebalanced once from measured shard times"
+            mine = plan[er]
         elif world > 1:
-            mine = capi.shard_plan(pb, world, max(1, K))[rank]
+            plan = capi.shard_plan(pb, world, max(1, K))
+            if args.rebalance:
+                # One step of measured rebalancing, part of the set-up: what the prediction cannot see (how many K tiles the
+                # zero extents leave at these parameters) is in the time a shard's call takes.  Every rank times a few calls
+                # of its predicted shard, the times are gathered, every rank derives the same corrected plan.
+                probe = capi.Context(shard_of(plan[rank]), max_categories=max(1, K), device=device)
+                for _ in range(2):
+                    probe.score(pr, alpha=args.alpha)
+                t0p = time.perf_counter()
+                for _ in range(3):
+                    probe.score(pr, alpha=args.alpha)
+                mine_ms = (time.perf_counter() - t0p) / 3 * 1e3
+                probe.close()
+                tt = torch.zeros(world, dtype=torch.float64, device="cuda" if native_comm else "cpu")
+                tt[rank] = mine_ms
+                dist.all_reduce(tt)
+                times = [float(x) for x in tt.cpu().numpy()]
+                plan = capi.rebalanced_plan(pb, plan, times, max(1, K))
+                plan_note = "rebalanced once from measured shard times %s ms" % [round(x, 2) for x in times]
+            mine = plan[rank]
         else:
             mine = np.arange(F)
-        shard = pb if len(mine) == F and world == 1 else dataclasses.replace(
-            pb, counts=np.ascontiguousarray(pb.counts[mine]), family_ids=[pb.family_ids[i] for i in mine])
+        shard = pb if len(mine) == F and world == 1 else shard_of(mine)
         ctx = capi.Context(shard, max_categories=max(1, K), device=device)
         ctx.set_profiling(True)
         if native_comm:
@@ -407,6 +437,8 @@ def main():
         }
         if n_gpus > 1:
             out["roofline"]["note"] = "rank 0's shard"
+        if n_gpus > 1 or args.emulate_shard:
+            out["config"]["shard_plan"] = plan_note or "predicted device time (cafe_shard_plan)"
         if world == 1 and sharded is None and not args.emulate_shard:
             if not args.no_cpu_baseline:
                 res = ctx.family_results(K if K > 1 else 0)

@@ -67,7 +67,7 @@ EXPORTS = [
     "cafe_finish_partial", "cafe_family_results", "cafe_get_matrix", "cafe_get_root_likelihoods", "cafe_get_stats",
     "cafe_matrix_size", "cafe_build_matrices", "cafe_probe_fp64_mfma", "cafe_set_profiling", "cafe_debug_stamps",
     "cafe_root_max", "cafe_reconstruct", "cafe_branch_probabilities", "cafe_pvalues", "cafe_debug_force_tile",
-    "cafe_comm_unique_id", "cafe_comm_attach", "cafe_comm_detach", "cafe_shard_plan", "cafe_create_sharded",
+    "cafe_comm_unique_id", "cafe_comm_attach", "cafe_comm_detach", "cafe_shard_plan", "cafe_shard_plan_scaled", "cafe_create_sharded",
     "cafe_sharded_destroy", "cafe_sharded_last_error", "cafe_sharded_score", "cafe_sharded_family_results",
     "cafe_sharded_size", "cafe_sharded_context", "cafe_set_graphs", "cafe_executed_flops", "cafe_get_extents", "cafe_debug_launch_flops", "cafe_debug_launch_ms", "cafe_debug_plan_check",
 ]
@@ -223,17 +223,36 @@ def _c_params(pr: Params, alpha: float = 1.0):
     return cp, keep
 
 
-def shard_plan(pb: Problem, n_shards: int, max_categories: int = 1):
-    """cafe_shard_plan: the library's balanced family partition (host code, no GPU needed).
+def shard_plan(pb: Problem, n_shards: int, max_categories: int = 1, family_scale=None):
+    """cafe_shard_plan / cafe_shard_plan_scaled: the library's balanced family partition (host code, no GPU needed).
+    family_scale: per family (table order), measured time of its shard under an earlier plan / mean over that plan's shards.
     Returns the family indices of every shard (a list of n_shards int64 arrays)."""
     keep = []
     cp = _c_problem(pb, keep, max_categories)
     order = np.empty(pb.n_families, dtype=np.int64)
     bounds = np.empty(n_shards + 1, dtype=np.int64)
-    rc = load().cafe_shard_plan(C.byref(cp), n_shards, order.ctypes.data_as(C.POINTER(C.c_int64)), bounds.ctypes.data_as(C.POINTER(C.c_int64)))
+    L = load()
+    if family_scale is None:
+        rc = L.cafe_shard_plan(C.byref(cp), n_shards, order.ctypes.data_as(C.POINTER(C.c_int64)), bounds.ctypes.data_as(C.POINTER(C.c_int64)))
+    else:
+        fs = np.ascontiguousarray(family_scale, dtype=np.float64)
+        assert fs.shape == (pb.n_families,)
+        L.cafe_shard_plan_scaled.restype = C.c_int
+        L.cafe_shard_plan_scaled.argtypes = [C.POINTER(CafeProblem), C.c_int32, _f64p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        rc = L.cafe_shard_plan_scaled(C.byref(cp), n_shards, _p(fs, _f64p), order.ctypes.data_as(C.POINTER(C.c_int64)), bounds.ctypes.data_as(C.POINTER(C.c_int64)))
     if rc:
         raise CafeError("cafe_shard_plan failed with code %d" % rc)
     return [order[bounds[r]:bounds[r + 1]].copy() for r in range(n_shards)]
+
+
+def rebalanced_plan(pb: Problem, plan, times, max_categories: int = 1):
+    """One step of measured rebalancing: `times[r]` is what shard r of `plan` took; the new plan (same number of shards) is
+    made with every family scaled by its shard's time over the mean."""
+    t = np.asarray(times, dtype=np.float64)
+    scale = np.ones(pb.n_families)
+    for r, fam in enumerate(plan):
+        scale[fam] = t[r] / t.mean()
+    return shard_plan(pb, len(plan), max_categories, family_scale=scale)
 
 
 def comm_unique_id() -> bytes:

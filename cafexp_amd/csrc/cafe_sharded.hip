@@ -78,10 +78,14 @@ struct ShardModel {
     std::vector<int> nodes;                        // interior non-root nodes
     std::vector<std::vector<int64_t>> prev;        // [nodes.size()][F]
     std::vector<std::vector<float>> weight;        // [nodes.size()][F] cost of the position's column at that node (see shard_cost)
+    std::vector<double> fam_cum;                   // [F + 1] prefix sums of the per-family term (5 columns' worth x the family's scale)
     int rows_inner = 0, rows_root = 0, categories = 1;
 };
 
-int build_shard_model(const cafe_problem* p, ShardModel& m) {
+// family_scale (or nullptr): a measured correction per family, table order -- the time a shard of an earlier plan took over
+// the mean of its plan's shards, for every family of that shard (cafe_shard_plan_scaled): multiplies whatever the family
+// contributes to a shard's predicted time.
+int build_shard_model(const cafe_problem* p, ShardModel& m, const double* family_scale = nullptr) {
     const int rc = read_tree(p, m.tree);
     if (rc != CAFE_OK) return rc;
     const int T = p->n_taxa;
@@ -128,6 +132,7 @@ int build_shard_model(const cafe_problem* p, ShardModel& m) {
             int32_t big = 0;                           // largest count under v: K2 skips the all-zero rows of a column tile, and
             for (int t : under) big = std::max(big, p->counts[m.order[i] * T + t]);   // columns of large families have few
             wt[i] = 1.0f + 2.0f * (float)std::max(0, big - 100) / (float)std::max(1, p->max_family_size);
+            if (family_scale) wt[i] *= (float)family_scale[m.order[i]];
             std::string ks(reinterpret_cast<const char*>(key.data()), sizeof(int32_t) * kw);
             auto it = seen.find(ks);
             if (it == seen.end()) {
@@ -144,6 +149,8 @@ int build_shard_model(const cafe_problem* p, ShardModel& m) {
         m.prev.push_back(std::move(pv));
         m.weight.push_back(std::move(wt));
     }
+    m.fam_cum.assign(F + 1, 0.0);
+    for (int64_t i = 0; i < F; ++i) m.fam_cum[i + 1] = m.fam_cum[i] + 5.0 * (family_scale ? family_scale[m.order[i]] : 1.0);
     return CAFE_OK;
 }
 
@@ -167,7 +174,7 @@ double shard_cost(const ShardModel& m, int64_t a, int64_t b) {
         for (int64_t i = a; i < b; ++i) cols += pv[i] < a ? wt[i] : 0.0f;
         cost += cols + 64.0 + 200.0;
     }
-    return cost + 5.0 * (double)(b - a);
+    return cost + (m.fam_cum[b] - m.fam_cum[a]);
 }
 
 int plan_shards(const ShardModel& m, int n_shards, std::vector<int64_t>& bounds) {
@@ -325,10 +332,17 @@ int cafe_comm_detach(cafe_ctx* ctx) {
 }
 
 int cafe_shard_plan(const cafe_problem* problem, int32_t n_shards, int64_t* order, int64_t* bounds) {
+    return cafe_shard_plan_scaled(problem, n_shards, nullptr, order, bounds);
+}
+
+int cafe_shard_plan_scaled(const cafe_problem* problem, int32_t n_shards, const double* family_scale, int64_t* order, int64_t* bounds) {
     if (!problem || !order || !bounds || n_shards < 1) return CAFE_ERR_ARGUMENT;
+    if (family_scale)
+        for (int64_t f = 0; f < problem->n_families; ++f)
+            if (!(family_scale[f] > 0.1 && family_scale[f] < 10.0)) return CAFE_ERR_ARGUMENT;
     try {
         cafe::ShardModel m;
-        int rc = cafe::build_shard_model(problem, m);
+        int rc = cafe::build_shard_model(problem, m, family_scale);
         if (rc != CAFE_OK) return rc;
         std::vector<int64_t> b;
         rc = cafe::plan_shards(m, n_shards, b);

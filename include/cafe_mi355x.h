@@ -175,6 +175,11 @@ int cafe_comm_detach(cafe_ctx* ctx);
  * order[bounds[r] .. bounds[r+1]).  Pure host code (no device needed); deterministic, so every rank derives the same
  * plan.  Only tree, counts and max sizes of `problem` are read. */
 int cafe_shard_plan(const cafe_problem* problem, int32_t n_shards, int64_t* order, int64_t* bounds);
+/* The same with a measured correction: family_scale[n_families] (table order), each in (0.1, 10).  After a few calls under
+ * a first plan every rank knows how long its shard took; scale = that time / the mean over the ranks, for every family of
+ * the shard, and the plan made with it moves the cuts so that the shards that ran long get less (what the prediction cannot
+ * see -- how many K tiles a column's zero extent leaves at this lambda -- is in the measurement).  NULL: cafe_shard_plan. */
+int cafe_shard_plan_scaled(const cafe_problem* problem, int32_t n_shards, const double* family_scale, int64_t* order, int64_t* bounds);
 
 /* (2) one process, several GPUs: cafe_create_sharded plans the shards (cafe_shard_plan), creates one context per device
  *     of `devices` -- each driven by its own host thread and stream -- and joins them in one communicator

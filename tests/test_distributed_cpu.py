@@ -145,3 +145,20 @@ def test_bench_parent_starts_its_ranks_without_touching_the_gpu():
     cmd = seen["cmd"]
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
     assert "127.0.0.1" in cmd and os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+
+
+def test_scaled_plan_moves_the_cuts_towards_the_shards_that_ran_long():
+    """cafe_shard_plan_scaled: families of a shard that took longer than the mean weigh more in the next plan, so that shard
+    gets fewer of them (and the plan stays a partition in the same family order); a scale of one everywhere reproduces
+    cafe_shard_plan; scales outside (0.1, 10) are refused."""
+    from cafexp_amd import capi, synth
+    pb, _ = synth.make_problem(n_taxa=12, n_families=3000, max_count=90, lam_sim=0.003, seed=4, root_cap=50)
+    plan = capi.shard_plan(pb, 4, 2)
+    same = capi.shard_plan(pb, 4, 2, family_scale=np.ones(pb.n_families))
+    assert all(np.array_equal(a, b) for a, b in zip(plan, same))
+    again = capi.rebalanced_plan(pb, plan, [1.0, 1.0, 1.0, 1.3], 2)
+    assert np.array_equal(np.concatenate(again), np.concatenate(plan))            # same order, other cuts
+    assert len(again[3]) < len(plan[3]) and sum(len(x) for x in again) == pb.n_families
+    assert len(again[0]) >= len(plan[0])
+    with pytest.raises(capi.CafeError):
+        capi.shard_plan(pb, 4, 2, family_scale=np.full(pb.n_families, 20.0))
