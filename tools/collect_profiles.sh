@@ -28,7 +28,7 @@ find $OUT/prof $OUT/prof_mammals -name "*kernel_trace.csv" -delete
 cd $R
 tail -1 $OUT/bench_full.json | cut -c1-300
 echo "[7/8] eight shards, one after the other (what each rank of an 8-GPU run does)"
-bash tools/shard_rehearsal.sh 8 | tail -1
+bash tools/shard_rehearsal.sh 8 | tail -4
 echo "[8/8] the launcher path: python bench.py --gpus 2 (gloo rehearsal, both ranks on this GPU)"
 timeout -k 10 300 python3 bench.py --gpus 2 --backend gloo --steps 3 --no-cpu-baseline > $OUT/bench_gloo2.json 2> $OUT/bench_gloo2.err
 cut -c1-200 $OUT/bench_gloo2.json
