@@ -726,6 +726,7 @@ def test_second_stream_for_the_roots_other_subtree_changes_no_bit(capi, oracle, 
         prs = [(P.Params(lambdas=np.array([l]), prior=P.prior_uniform(pb.max_root_family_size), multipliers=mult, cat_probs=probs, error_model=em), 0.8)
                for l in (0.004, 0.0007)]
         prs.append((P.Params(lambdas=np.array([0.002]), prior=P.prior_uniform(pb.max_root_family_size), error_model=em), 1.0))
+        monkeypatch.setenv("CAFE_STREAMS", "1")
         one = capi.Context(pb, max_categories=4)
         monkeypatch.setenv("CAFE_STREAMS", "2")
         two = capi.Context(pb, max_categories=4)
