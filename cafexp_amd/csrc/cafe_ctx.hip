@@ -1011,7 +1011,7 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
                     g.map[j] = c->d_edge_map[op.src_child[j]];
                 }
                 // (the root's vector is read whole by the reduction and has no extent record)
-                g.tileext = c->panel_extents && op.n_src > 0 && !op.to_root && !c->no_asm_skip ? c->d_tileext[op.parent] : nullptr;
+                g.tileext = c->panel_extents && !op.to_root && !c->no_asm_skip ? c->d_tileext[op.parent] : nullptr;
                 HIP_TRY(c, launch_leaf_gather(g, K, ls));
             } else {
                 GemmArgs g{};

@@ -81,6 +81,19 @@ __global__ __launch_bounds__(256) void leaf_gather_fast_kernel(const GatherArgs 
     const int f = (blockIdx.x * 256 + threadIdx.x) * 2;
     if (f >= a.ld) return;
     const int r0 = blockIdx.y * kFastRows;
+    if (a.tileext) {
+        // rows outside the zero extents of the workgroup's (up to four) 128-column tiles are never staged by K2 (see the
+        // assemble pass below): leave them as they are
+        const int n_ct = a.ld / kBN, ct0 = (blockIdx.x * 512) / kBN;
+        int lo = 0x7fffffff, hi = -1;
+        for (int ct = ct0; ct < ct0 + 4 && ct < n_ct; ++ct) {
+            const int32_t* te = a.tileext + ((int64_t)cat * n_ct + ct) * 2;
+            const bool some = te[1] >= te[0];
+            lo = min(lo, some ? te[0] : 0);
+            hi = max(hi, some ? te[1] : 0);
+        }
+        if (r0 + kFastRows - 1 < (lo & ~15) || r0 > (hi | 15)) return;
+    }
     const unsigned ldp = (unsigned)a.pool.ld;
     double* __restrict__ dst = a.dst + (int64_t)cat * a.panel_kstride + (int64_t)r0 * a.ld + f;
     constexpr int NL = NLEAF > 0 ? NLEAF : 1;               // (zero-length arrays are not allowed)
