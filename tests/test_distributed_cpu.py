@@ -104,7 +104,10 @@ def _worker(rank, world, port, case, out):
 def test_two_rank_shards_allreduce_to_the_whole(case):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + {"base": 0, "gamma": 1, "reject": 2}[case]
+    import socket
+    with socket.socket() as sk:                              # a port nobody holds right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q)) for r in range(2)]
     for p in procs:
         p.start()
