@@ -226,6 +226,7 @@ def main():
     under_launcher = "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not under_launcher and not args.single_process and not args.emulate_shard:
         sys.exit(launch_ranks(args))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # (dmabuf IPC: RCCL across processes needs it on this driver)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
