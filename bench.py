@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip one_column_per_family and other_configs (N = 1 only)")
     ap.add_argument("--single-process", action="store_true", help="N > 1: one process drives all GPUs (cafe_create_sharded)")
     ap.add_argument("--emulate-shard", default="", help="R/W: rehearsal on one GPU of what rank R of W would run (no collective)")
+    ap.add_argument("--force-comm", action="store_true", help="diagnostic, under a launcher with ONE rank: take the N > 1 path (process group, "
+                    "communicator inside the library, all-reduce in cafe_score) on a one-GPU box")
     ap.add_argument("--shard-times", default="", help="with --emulate-shard: ms per shard measured under the default plan (comma list): "
                     "use the plan rebalanced by them, as the ranks of an N > 1 run do after their first calls")
     ap.add_argument("--rebalance", action="store_true", help="N > 1: one step of measured rebalancing during set-up (every rank times a few "
@@ -241,11 +243,12 @@ def main():
     from cafexp_amd import capi, problem as P, synth
     from cafexp_amd.gamma_rates import discrete_gamma
 
-    native_comm = world > 1 and args.backend == "nccl"
+    dist_on = world > 1 or args.force_comm            # (--force-comm: the N > 1 code path with a world of one rank, for a one-GPU box)
+    native_comm = dist_on and args.backend == "nccl"
     lib_reduce = native_comm                          # the all-reduce is issued inside cafe_score (cafe_comm_attach)
     device = local_rank % max(1, torch.cuda.device_count()) if native_comm or world == 1 else 0
     torch.cuda.set_device(device)
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if native_comm:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
@@ -280,7 +283,7 @@ def main():
                 plan = capi.rebalanced_plan(pb, plan, [float(x) for x in args.shard_times.split(",")], max(1, K))
                 plan_note = "rebalanced once from measured shard times"
             mine = plan[er]
-        elif world > 1:
+        elif dist_on:
             plan = capi.shard_plan(pb, world, max(1, K))
             if args.rebalance:
                 # One step of measured rebalancing, part of the set-up: what the prediction cannot see (how many K tiles the
@@ -346,7 +349,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -354,7 +357,7 @@ def main():
     # six times shorter and the 200 events cost it 2 % (0.5 ms; 0.3 ms = 0.2 % of the whole table's call), so the ranks of an
     # N > 1 run (and the one-GPU rehearsal of a rank) time their steps without events and take the per-launch figures from one
     # more, profiled, step behind the timed region (`roofline.measured`).
-    live_events = world == 1 and sharded is None and not args.emulate_shard
+    live_events = not dist_on and sharded is None and not args.emulate_shard
     if not live_events:
         for r in range(n_gpus if sharded is not None else 1):
             (sharded.shard(r) if sharded is not None else ctx).set_profiling(False)
@@ -389,7 +392,7 @@ def main():
         fence()
     # what the K2 launches of a step really executed (the same every step: same parameters); counted once, outside the timing
     flops_executed = ctx.executed_flops() * n_prof
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if native_comm else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -438,9 +441,9 @@ def main():
         }
         if n_gpus > 1:
             out["roofline"]["note"] = "rank 0's shard"
-        if n_gpus > 1 or args.emulate_shard:
+        if dist_on or n_gpus > 1 or args.emulate_shard:
             out["config"]["shard_plan"] = plan_note or "predicted device time (cafe_shard_plan)"
-        if world == 1 and sharded is None and not args.emulate_shard:
+        if not dist_on and sharded is None and not args.emulate_shard:
             if not args.no_cpu_baseline:
                 res = ctx.family_results(K if K > 1 else 0)
                 res["matrix"] = ctx.matrix
@@ -490,7 +493,7 @@ def main():
                                                    "identical_to_headline": two["2"][1] == value and two["1"][1] == value}
                 out["other_configs"] = other_configs(args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         if lib_reduce:
             ctx.comm_detach()

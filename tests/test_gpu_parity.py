@@ -739,3 +739,24 @@ def test_second_stream_for_the_roots_other_subtree_changes_no_bit(capi, oracle, 
                 assert v1 == v2
                 for key in r1:
                     assert np.array_equal(r1[key], r2[key]), key
+
+
+@pytest.mark.gpu
+def test_bench_rank_path_under_a_launcher_with_one_rank():
+    """What every rank of `bench.py --gpus N` does -- nccl process group, the communicator id over the launcher's channel,
+    cafe_comm_attach, the all-reduce inside cafe_score, the max over ranks, detach -- on a one-GPU box: a world of ONE rank
+    under torch.distributed.run (--force-comm), on a small table; the value is the single-process one."""
+    import subprocess, sys, os, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--families", "3000", "--taxa", "20", "--max-count", "250", "--categories", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", "1",
+                        os.path.join(root, "bench.py"), "--gpus", "1", "--force-comm", "--rebalance"] + common,
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "inside cafe_score" in d["config"]["parallelism"] and d["config"]["shard_plan"].startswith("rebalanced")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    one = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["neg_lnl"] == one["neg_lnl"] and math.isfinite(d["neg_lnl"])
