@@ -73,11 +73,9 @@ def parse():
 
 def launch_ranks(args):
     """N > 1 and not under a launcher: start the ranks as children BEFORE anything here touches the GPU."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # the launcher owns the rendezvous port (--standalone: a c10d store on a port it binds itself), no bind-close-reuse race
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
@@ -338,14 +336,24 @@ def main():
         if sharded is not None:
             return sharded.score(pr, alpha=args.alpha)
         if world == 1 or lib_reduce:
-            return ctx.score(pr, alpha=args.alpha)    # N > 1: ends with the library's ncclAllReduce of {sum lnL, rejects}
-        ctx.score_partial(pr, buf.data_ptr(), stream.cuda_stream, alpha=args.alpha)
+            return ctx.score(pr, alpha=args.alpha)    # N > 1: ends with the library's ncclAllReduce of {sum lnL, rejects}; ranks fail together
+        # the pair is reduced from here.  A rank whose call fails leaves {0, NaN} in its pair and STILL takes part in the
+        # reduction, so that every rank reads NaN and raises instead of waiting for it.
+        err = None
+        try:
+            ctx.score_partial(pr, buf.data_ptr(), stream.cuda_stream, alpha=args.alpha)
+        except capi.CafeError as e:
+            err = e
         if native_comm:                               # (only if cafe_comm_attach failed) RCCL all-reduce issued by torch
             dist.all_reduce(buf)
-            return ctx.finish(buf.cpu().numpy())
-        pair = buf.cpu()                              # gloo rehearsal
-        dist.all_reduce(pair)
-        return ctx.finish(pair.numpy())
+            pair = buf.cpu().numpy()
+        else:
+            pair = buf.cpu()                          # gloo rehearsal
+            dist.all_reduce(pair)
+            pair = pair.numpy()
+        if err is not None or pair[1] != pair[1]:
+            raise RuntimeError("rank %d: %s" % (rank, err if err is not None else "another rank's call failed (poisoned pair)"))
+        return ctx.finish(pair)
 
     def fence():
         torch.cuda.synchronize()

@@ -70,6 +70,7 @@ EXPORTS = [
     "cafe_comm_unique_id", "cafe_comm_attach", "cafe_comm_detach", "cafe_shard_plan", "cafe_shard_plan_scaled", "cafe_create_sharded",
     "cafe_sharded_destroy", "cafe_sharded_last_error", "cafe_sharded_score", "cafe_sharded_family_results",
     "cafe_sharded_size", "cafe_sharded_context", "cafe_set_graphs", "cafe_executed_flops", "cafe_get_extents", "cafe_debug_launch_flops", "cafe_debug_launch_ms", "cafe_debug_plan_check",
+    "cafe_debug_fail_next",
 ]
 CAFE_COMM_ID_BYTES = 128
 
@@ -167,6 +168,8 @@ def load():
     L.cafe_sharded_size.argtypes = [C.c_void_p]
     L.cafe_sharded_context.restype = C.c_void_p
     L.cafe_sharded_context.argtypes = [C.c_void_p, C.c_int32]
+    L.cafe_debug_fail_next.restype = C.c_int
+    L.cafe_debug_fail_next.argtypes = [C.c_void_p, C.c_int]
     _lib = L
     return L
 
@@ -458,6 +461,10 @@ class Context:
 
     def set_profiling(self, on: bool):
         self._check(self._lib.cafe_set_profiling(self._h, 1 if on else 0))
+
+    def debug_fail_next(self, n: int = 1):
+        """Test hook: the n-th next call of this context fails with CAFE_ERR_DEVICE in the middle of its enqueue."""
+        self._check(self._lib.cafe_debug_fail_next(self._h, n))
 
     def set_graphs(self, on: bool):
         """False: enqueue every call launch by launch instead of replaying its captured hipGraph."""

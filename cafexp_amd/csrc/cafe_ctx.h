@@ -112,6 +112,12 @@ struct cafe_ctx {
     void* comm = nullptr;                    // ncclComm_t
     bool comm_owned = false;
     int comm_world = 1, comm_rank = 0;
+    // A call on a context with a communicator is collective.  A rank whose own enqueue fails still enters the all-reduce,
+    // with rejects = NaN (h_poison), so that every rank returns an error instead of waiting for it; a rank that is gone
+    // altogether is caught by the deadline below (the waiting ranks abort their communicator and return CAFE_ERR_DEVICE).
+    double comm_timeout_s = 120.0;           // CAFE_COMM_TIMEOUT_S at cafe_comm_attach / cafe_create_sharded; <= 0: wait for ever
+    double* h_poison = nullptr;              // pinned {0, NaN}
+    int debug_fail_in = 0;                   // cafe_debug_fail_next: the n-th next enqueue fails behind its K1 launch
 
     // last call
     std::vector<int> slot_of;               // [node*Kmax + k]
@@ -212,5 +218,9 @@ int enqueue_rootmax(cafe_ctx* c, const double* lambdas, hipStream_t s);
 // multi-GPU (cafe_sharded.hip)
 int comm_allreduce_pair(cafe_ctx* c, double* d_pair, hipStream_t s);
 void comm_release(cafe_ctx* c);
+// waits for `s`; with a communicator attached: under the deadline comm_timeout_s and watching the communicator's
+// asynchronous error state -- on either the communicator is aborted and CAFE_ERR_DEVICE returned
+int comm_wait_stream(cafe_ctx* c, hipStream_t s);
+void comm_abort(cafe_ctx* c);
 
 }  // namespace cafe

@@ -571,7 +571,10 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
         HIP_TRY(c, hipHostMalloc(&c->h_stage, c->stage_bytes, hipHostMallocDefault));
         std::memset(c->h_stage, 0, c->stage_bytes);
     }
-    HIP_TRY(c, hipHostMalloc(&c->h_result, 2 * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc(&c->h_result, 4 * sizeof(double), hipHostMallocDefault));
+    c->h_poison = c->h_result + 2;                       // what a failing rank of a communicator feeds the all-reduce
+    c->h_poison[0] = 0.0;
+    c->h_poison[1] = std::numeric_limits<double>::quiet_NaN();
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
     for (auto& e : c->ev) HIP_TRY(c, hipEventCreate(&e));
     {
@@ -870,6 +873,10 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
     if (events) HIP_TRY(c, hipEventRecord(c->ev[0], s));
     HIP_TRY(c, launch_bd_matrix_build_both(c->pool, c->kpool, c->d_slots, c->d_slots + c->max_slots, c->n_slots_last, c->n_kslots_last, s));
     if (events) HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    if (c->debug_fail_in > 0 && --c->debug_fail_in == 0) {                     // test hook: a device error in the middle of a call
+        set_err(c, "injected failure (cafe_debug_fail_next)");
+        return CAFE_ERR_DEVICE;
+    }
     const bool have_ext = c->h_ext && c->h_ext_valid && c->h_ext_K == K;       // the previous call's extents (same shape)
     std::vector<int32_t> prev_ext;
     if (have_ext) prev_ext.assign(c->h_ext, c->h_ext + (size_t)2 * c->n_kslots_last * c->kpool.ext_blocks);
@@ -1300,6 +1307,7 @@ void cafe_destroy(cafe_ctx* ctx) {
 const char* cafe_last_error(const cafe_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 double cafe_finish_partial(const double hp[2]) {
+    if (std::isnan(hp[1])) return std::numeric_limits<double>::quiet_NaN();     // a shard failed its call (poisoned pair)
     if (hp[1] > 0) return std::numeric_limits<double>::infinity();
     return -hp[0];
 }
@@ -1307,12 +1315,21 @@ double cafe_finish_partial(const double hp[2]) {
 int cafe_score_partial(cafe_ctx* ctx, const cafe_params* params, double* device_partial, void* hip_stream) {
     if (!ctx) return CAFE_ERR_ARGUMENT;
     if (!device_partial) { set_err(ctx, "cafe_score_partial: device_partial is NULL"); return CAFE_ERR_ARGUMENT; }
+    int rc;
     try {
-        return enqueue(ctx, params, device_partial, (hipStream_t)hip_stream);
+        rc = enqueue(ctx, params, device_partial, (hipStream_t)hip_stream);
     } catch (const std::exception& e) {
         set_err(ctx, "cafe_score_partial: %s", e.what());
-        return CAFE_ERR_MEMORY;
+        rc = CAFE_ERR_MEMORY;
     }
+    // the caller owns the collective: a failed shard leaves rejects = NaN in its pair (best effort), so that a reduction over
+    // the shards reads NaN on every rank (cafe_finish_partial returns NaN) even if this return code goes unread
+    if (rc != CAFE_OK && ctx->h_poison && ctx->device_ready) {
+        (void)hipMemcpyAsync(device_partial, ctx->h_poison, 2 * sizeof(double), hipMemcpyHostToDevice, (hipStream_t)hip_stream);
+        (void)hipStreamSynchronize((hipStream_t)hip_stream);        // whatever the failed call left in flight (its upload reads h_stage)
+        ctx->upload_pending = false;
+    }
+    return rc;
 }
 
 int cafe_score(cafe_ctx* ctx, const cafe_params* params, double* neg_lnl, const cafe_family_out* out) {
@@ -1324,21 +1341,54 @@ int cafe_score(cafe_ctx* ctx, const cafe_params* params, double* neg_lnl, const 
         rc = enqueue(ctx, params, ctx->d_result, ctx->stream);
     } catch (const std::exception& e) {
         set_err(ctx, "cafe_score: %s", e.what());
-        return CAFE_ERR_MEMORY;
+        rc = CAFE_ERR_MEMORY;
     }
-    if (rc != CAFE_OK) return rc;
+    if (rc != CAFE_OK) {
+        if (!ctx->comm) {
+            if (ctx->device_ready && ctx->stream) (void)hipStreamSynchronize(ctx->stream);   // what the failed call left in flight
+            ctx->upload_pending = false;
+            return rc;
+        }
+        // The call is collective: the other ranks are in the all-reduce or on their way into it, whatever went wrong here
+        // (a HIP error, an allocation, an exception -- argument errors are the same on every rank, but nothing relies on
+        // that).  Enter it with rejects = NaN: every rank then reads NaN and returns an error.  If even that cannot be
+        // enqueued, abort the communicator; the others run into their deadline (comm_wait_stream).
+        const std::string first = ctx->err;
+        bool sent = hipSetDevice(ctx->device) == hipSuccess &&
+                    hipMemcpyAsync(ctx->d_result, ctx->h_poison, 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                    comm_allreduce_pair(ctx, ctx->d_result, ctx->stream) == CAFE_OK;
+        if (sent) sent = comm_wait_stream(ctx, ctx->stream) == CAFE_OK;
+        if (!sent) comm_abort(ctx);
+        ctx->upload_pending = false;
+        ctx->have_results = false;
+        set_err(ctx, "%s [rank %d of %d; the other ranks were %s]", first.c_str(), ctx->comm_rank, ctx->comm_world,
+                sent ? "told through the all-reduce" : "NOT told: communicator aborted");
+        return rc;
+    }
     rc = comm_allreduce_pair(ctx, ctx->d_result, ctx->stream);          // family shards on other GPUs: one RCCL all-reduce
-    if (rc != CAFE_OK) return rc;
+    if (rc != CAFE_OK) { comm_abort(ctx); return rc; }
     // without a communicator K4's last kernel has already written the pair to h_result (a host-only rejection went
     // through a copy into d_result instead)
     if (ctx->comm || ctx->last_rejected)
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    rc = comm_wait_stream(ctx, ctx->stream);
+    if (rc != CAFE_OK) return rc;
     ctx->upload_pending = false;
+    if (ctx->comm && std::isnan(ctx->h_result[1])) {                    // (rejects is a sum of family weights: never NaN by itself)
+        ctx->have_results = false;
+        set_err(ctx, "cafe_score: another rank of the communicator failed its call (rank %d of %d read the poisoned pair)", ctx->comm_rank, ctx->comm_world);
+        return CAFE_ERR_DEVICE;
+    }
     *neg_lnl = cafe_finish_partial(ctx->h_result);
     ctx->stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     collect_stats(ctx);
     if (out) return cafe_family_results(ctx, out);
+    return CAFE_OK;
+}
+
+int cafe_debug_fail_next(cafe_ctx* ctx, int n) {
+    if (!ctx || n < 0) return CAFE_ERR_ARGUMENT;
+    ctx->debug_fail_in = n;
     return CAFE_OK;
 }
 

@@ -9,6 +9,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -32,6 +33,47 @@ int comm_allreduce_pair(cafe_ctx* c, double* d_pair, hipStream_t s) {
     const ncclResult_t r = ncclAllReduce(d_pair, d_pair, 2, ncclDouble, ncclSum, (ncclComm_t)c->comm, s);
     if (r != ncclSuccess) { set_err(c, "ncclAllReduce failed: %s", ncclGetErrorString(r)); return CAFE_ERR_DEVICE; }
     return CAFE_OK;
+}
+
+// The communicator is unusable (a peer is gone, or this rank could not even enqueue its part): abort it, so that whatever
+// this rank still has in flight on it ends and cafe_destroy does not block in ncclCommDestroy.
+void comm_abort(cafe_ctx* c) {
+    if (c->comm && c->comm_owned) (void)ncclCommAbort((ncclComm_t)c->comm);
+    c->comm = nullptr;
+    c->comm_owned = false;
+    c->comm_world = 1;
+    c->comm_rank = 0;
+}
+
+int comm_wait_stream(cafe_ctx* c, hipStream_t s) {
+    if (!c->comm || !(c->comm_timeout_s > 0)) { HIP_TRY(c, hipStreamSynchronize(s)); return CAFE_OK; }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return CAFE_OK;
+        if (e != hipErrorNotReady) { set_err(c, "hipStreamQuery failed: %s", hipGetErrorString(e)); comm_abort(c); return CAFE_ERR_DEVICE; }
+        if ((spin & 63) == 63) {
+            ncclResult_t async = ncclSuccess;
+            if (ncclCommGetAsyncError((ncclComm_t)c->comm, &async) == ncclSuccess && async != ncclSuccess && async != ncclInProgress) {
+                set_err(c, "cafe_score: the communicator reports %s (rank %d of %d); aborted", ncclGetErrorString(async), c->comm_rank, c->comm_world);
+                comm_abort(c);
+                return CAFE_ERR_DEVICE;
+            }
+            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (waited > c->comm_timeout_s) {
+                set_err(c, "cafe_score: the all-reduce did not complete within %.0f s (CAFE_COMM_TIMEOUT_S): a rank of the communicator "
+                           "is gone or never made this call (rank %d of %d); communicator aborted", c->comm_timeout_s, c->comm_rank, c->comm_world);
+                comm_abort(c);
+                return CAFE_ERR_DEVICE;
+            }
+            if (waited > 0.05) std::this_thread::sleep_for(std::chrono::microseconds(200));   // a call is milliseconds: past that, stop spinning
+        }
+    }
+}
+
+static double comm_timeout_from_env() {
+    const char* e = std::getenv("CAFE_COMM_TIMEOUT_S");
+    return e ? std::atof(e) : 120.0;
 }
 
 void comm_release(cafe_ctx* c) {
@@ -321,6 +363,7 @@ int cafe_comm_attach(cafe_ctx* ctx, const char id[CAFE_COMM_ID_BYTES], int32_t w
     ctx->comm_owned = true;
     ctx->comm_world = world_size;
     ctx->comm_rank = rank;
+    ctx->comm_timeout_s = cafe::comm_timeout_from_env();
     return CAFE_OK;
 }
 
@@ -378,23 +421,31 @@ cafe_sharded* cafe_create_sharded(const cafe_problem* problem, const int32_t* de
         const int T = problem->n_taxa;
         std::vector<std::string> errs(n_devices);
         s->run_all([&](int r) {                              // the contexts are built concurrently, each by the thread that will drive it
-            const int64_t lo = s->bounds[r], n = s->bounds[r + 1] - lo;
-            std::vector<int32_t> counts((size_t)n * T);
-            for (int64_t i = 0; i < n; ++i) std::memcpy(&counts[(size_t)i * T], problem->counts + s->order[lo + i] * T, sizeof(int32_t) * T);
-            cafe_problem pb = *problem;
-            pb.counts = counts.data();
-            pb.n_families = n;
-            pb.device = s->devices[r];
-            char e[512] = {0};
-            s->ctx[r] = cafe_create(&pb, e, sizeof e);
-            if (!s->ctx[r]) errs[r] = e;
+            try {                                            // (an exception must not leave a worker thread: std::terminate)
+                const int64_t lo = s->bounds[r], n = s->bounds[r + 1] - lo;
+                std::vector<int32_t> counts((size_t)n * T);
+                for (int64_t i = 0; i < n; ++i) std::memcpy(&counts[(size_t)i * T], problem->counts + s->order[lo + i] * T, sizeof(int32_t) * T);
+                cafe_problem pb = *problem;
+                pb.counts = counts.data();
+                pb.n_families = n;
+                pb.device = s->devices[r];
+                char e[512] = {0};
+                s->ctx[r] = cafe_create(&pb, e, sizeof e);
+                if (!s->ctx[r]) errs[r] = e;
+            } catch (const std::exception& e) {
+                s->ctx[r] = nullptr;
+                errs[r] = e.what();
+            }
         });
         for (int r = 0; r < n_devices; ++r)
             if (!s->ctx[r]) { const std::string msg = "cafe_create_sharded: shard " + std::to_string(r) + ": " + errs[r]; cafe_sharded_destroy(s); return fail(msg); }
         std::vector<ncclComm_t> comms(n_devices);
         const ncclResult_t nr = ncclCommInitAll(comms.data(), n_devices, s->devices.data());
         if (nr != ncclSuccess) { const std::string msg = std::string("cafe_create_sharded: ncclCommInitAll failed: ") + ncclGetErrorString(nr); cafe_sharded_destroy(s); return fail(msg); }
-        for (int r = 0; r < n_devices; ++r) { s->ctx[r]->comm = comms[r]; s->ctx[r]->comm_owned = true; s->ctx[r]->comm_world = n_devices; s->ctx[r]->comm_rank = r; }
+        for (int r = 0; r < n_devices; ++r) {
+            s->ctx[r]->comm = comms[r]; s->ctx[r]->comm_owned = true; s->ctx[r]->comm_world = n_devices; s->ctx[r]->comm_rank = r;
+            s->ctx[r]->comm_timeout_s = cafe::comm_timeout_from_env();
+        }
     } catch (const std::exception& e) {
         if (s) cafe_sharded_destroy(s);
         return fail(std::string("cafe_create_sharded: ") + e.what());
@@ -421,9 +472,16 @@ int cafe_sharded_score(cafe_sharded* s, const cafe_params* params, double* neg_l
     std::vector<double> value(n, 0.0);
     // every worker: enqueue its shard, all-reduce the pair on its stream, read it back.  The all-reduce makes the call
     // collective; argument errors are detected identically on every shard before anything is enqueued.
-    s->run_all([&](int r) { rc[r] = cafe_score(s->ctx[r], params, &value[r], nullptr); });
+    // A shard whose own enqueue fails still enters the all-reduce (with a poisoned pair, cafe_score), so every worker comes
+    // back; the shard that failed first-hand keeps its own code and message, the others report "another rank failed".
+    s->run_all([&](int r) {
+        try { rc[r] = cafe_score(s->ctx[r], params, &value[r], nullptr); }
+        catch (const std::exception& e) { cafe::set_err(s->ctx[r], "cafe_sharded_score: %s", e.what()); rc[r] = CAFE_ERR_MEMORY; }
+    });
+    int bad = -1;
     for (int r = 0; r < n; ++r)
-        if (rc[r] != CAFE_OK) { s->err = "shard " + std::to_string(r) + ": " + cafe_last_error(s->ctx[r]); return rc[r]; }
+        if (rc[r] != CAFE_OK && (bad < 0 || std::strstr(cafe_last_error(s->ctx[bad]), "another rank"))) bad = r;
+    if (bad >= 0) { s->err = "shard " + std::to_string(bad) + ": " + cafe_last_error(s->ctx[bad]); return rc[bad]; }
     *neg_lnl = value[0];                                     // identical on every rank after the all-reduce
     if (out) return cafe_sharded_family_results(s, out);
     return CAFE_OK;
@@ -444,7 +502,8 @@ int cafe_sharded_family_results(cafe_sharded* s, const cafe_family_out* out) {
         if (out->category_likelihood) { cat.resize((size_t)nf * K); o.category_likelihood = cat.data(); }
         if (out->family_likelihood) { lik.resize(nf); o.family_likelihood = lik.data(); }
         if (out->failed) { failed.resize(nf); o.failed = failed.data(); }
-        rc[r] = cafe_family_results(s->ctx[r], &o);
+        try { rc[r] = cafe_family_results(s->ctx[r], &o); }
+        catch (const std::exception&) { rc[r] = CAFE_ERR_MEMORY; }
         if (rc[r] != CAFE_OK) return;
         const bool gamma = s->ctx[r]->model_last == CAFE_MODEL_GAMMA;
         for (int64_t i = 0; i < nf; ++i) {                   // shards write disjoint families

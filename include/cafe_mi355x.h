@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CAFE_ABI_VERSION 2
+#define CAFE_ABI_VERSION 3
 #define CAFE_MAX_CATEGORIES 32
 
 typedef struct cafe_ctx cafe_ctx;
@@ -150,7 +150,9 @@ int cafe_score(cafe_ctx* ctx, const cafe_params* params, double* neg_lnl, const 
  * torch.cuda.current_stream() is by default) and the call returns without synchronising, so that
  * the caller can all-reduce the pair across ranks (RCCL) on the same stream: SURVEY.md 8e. */
 int cafe_score_partial(cafe_ctx* ctx, const cafe_params* params, double* device_partial, void* hip_stream);
-/* Turns the all-reduced pair into the scorer value: +inf if partial[1] > 0 else -partial[0]. */
+/* Turns the all-reduced pair into the scorer value: +inf if partial[1] > 0 else -partial[0]; NaN if partial[1] is NaN --
+ * the mark of a shard whose call FAILED (cafe_score_partial returned an error: it then leaves {0, NaN} in its pair, best
+ * effort, so that every rank of the caller's reduction learns of it). */
 double cafe_finish_partial(const double host_partial[2]);
 
 /* ---- Multi-GPU: families shard across the GPUs of a node, every GPU builds all matrices, and ONE
@@ -162,7 +164,12 @@ double cafe_finish_partial(const double host_partial[2]);
  *     and hands it to the others by whatever channel the launcher offers, and every rank calls cafe_comm_attach.  From
  *     then on cafe_score on every rank ends with ncclAllReduce(pair, 2 doubles, sum) on the context's stream and returns
  *     the WHOLE table's value on every rank; per-family results stay per shard.  Calls are collective: every rank must
- *     make the same sequence of cafe_score calls. */
+ *     make the same sequence of cafe_score calls.  Ranks fail TOGETHER: a rank whose own call fails (HIP error,
+ *     allocation, bad argument) still enters the all-reduce, with rejects = NaN, keeps its own error code, and every
+ *     other rank returns CAFE_ERR_DEVICE ("another rank ... failed"); a rank that is gone altogether is caught by a
+ *     deadline on the wait (environment CAFE_COMM_TIMEOUT_S at attach, default 120 s; <= 0 waits for ever): the waiting
+ *     ranks abort their communicator (ncclCommAbort) and return CAFE_ERR_DEVICE.  After an abort the context has no
+ *     communicator any more (attach again, or use it on its own). */
 #define CAFE_COMM_ID_BYTES 128
 int cafe_comm_unique_id(char id[CAFE_COMM_ID_BYTES]);
 int cafe_comm_attach(cafe_ctx* ctx, const char id[CAFE_COMM_ID_BYTES], int32_t world_size, int32_t rank);
@@ -265,6 +272,9 @@ int cafe_set_profiling(cafe_ctx* ctx, int on);
 int cafe_set_graphs(cafe_ctx* ctx, int on);
 /* diagnostic: K2's row tile is 16*mi rows, mi = 4..9, normally chosen per launch; mi forces one, 0 restores the choice */
 int cafe_debug_force_tile(cafe_ctx* ctx, int mi);
+/* test hook: the n-th next call of this context (n >= 1; 0 disarms) fails with CAFE_ERR_DEVICE behind its K1 launch, as a
+ * HIP error in the middle of a call would -- pins the fail-together behaviour above */
+int cafe_debug_fail_next(cafe_ctx* ctx, int n);
 /* diagnostic (CAFE_GEMM_STAMPS=1 at cafe_create): per-block placement + timeline words of the last K2 launch */
 int cafe_debug_stamps(cafe_ctx* ctx, unsigned long long* out, size_t words);
 

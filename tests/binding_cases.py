@@ -15,6 +15,10 @@ CASES = {
     "score_gamma_rejected": dict(job="score", model="gamma", k=4, alpha=0.5, limit=200, **MAMMALS, **{"lambda": 0.002}),
     "score_synth20_lambda_tree": dict(job="score", tree="synth20_tree.txt", families="synth20_families.txt", per_family=1,
                                       lambdas="0.004,0.008", lambda_tree="synth20_lambda_tree.txt"),
+    # matrix order 751 (a count of 600: M 720, R 750); the error model's last row (maxcnt = 600) differs from the others and
+    # family 0 sits on it: error_model::get_probs at its own maximum (error_model.cpp:52-57) through the binding's table
+    "score_big12_lambda_tree_error_at_maxcnt": dict(job="score", tree="big12_tree.txt", families="big12_families.txt", per_family=1,
+                                                    lambdas="0.002,0.0035", lambda_tree="big12_lambda_tree.txt", errfile="errormodel_600.txt"),
     # ---- estimator::estimate_missing_variables: the reference's optimizer and scorers, fixed seed
     "search_lambda": dict(job="search", limit=400, seed=10, **MAMMALS),
     "search_two_lambdas": dict(job="search", limit=300, seed=11, lambda_tree="chimphuman_separate_lambda.txt", **MAMMALS),

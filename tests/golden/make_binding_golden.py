@@ -2,7 +2,7 @@
 """Generates tests/golden/ref_binding.json: the jobs of tests/binding_cases.py run by the UNMODIFIED reference
 (oracle/_ref/ref_harness, device=cpu) in the build container.  tests/test_reference_binding.py runs the same jobs on
 the GPU box through the reference-side binding (oracle/_ref/ref_hip_harness device=hip) and compares.
-    make -C oracle ref && python tests/golden/make_binding_golden.py
+    make -C oracle ref && python tests/golden/make_binding_golden.py [case ...]     (named cases only: the others are kept)
 Inputs + expected outputs only; no reference source is stored."""
 import json
 import os
@@ -21,7 +21,13 @@ D = os.path.join(HERE, "data")
 
 def main():
     out = {"generator": "tests/golden/make_binding_golden.py", "source": "oracle/_ref/ref_harness (real reference, CPU)", "cases": {}}
+    only = set(sys.argv[1:])
+    if only:
+        with open(os.path.join(HERE, "ref_binding.json")) as f:
+            out["cases"] = json.load(f)["cases"]
     for name, case in CASES.items():
+        if only and name not in only:
+            continue
         kv = {k: (os.path.join(D, v) if k in FILE_KEYS else v) for k, v in case.items() if k != "job"}
         t0 = time.time()
         r = O.ref(case["job"], **kv)

@@ -123,31 +123,36 @@ def test_two_rank_shards_allreduce_to_the_whole(case):
 
 def test_bench_parent_starts_its_ranks_without_touching_the_gpu():
     """`python bench.py --gpus N` run plainly must launch N ranks itself (the driver invokes it that way) and must do so
-    before importing torch / touching the GPU: checked on the launcher function's command line."""
-    sys.path.insert(0, ROOT)
-    import importlib
+    before importing torch / touching the GPU: in a FRESH interpreter, import bench, call its launcher with subprocess.run
+    replaced, and check that torch was never imported and what the command line is (the launcher owns the rendezvous port)."""
+    import json
     import subprocess
-    bench = importlib.import_module("bench")
-    seen = {}
-
-    def fake_run(cmd, **kw):
-        seen["cmd"] = cmd
-        class R:
-            returncode = 0
-            stdout = '{"metric": "x", "n_gpus": 4}\\n'
-        return R()
-    real = subprocess.run
-    subprocess.run = fake_run
-    try:
-        args = type("A", (), {"gpus": 4})()
-        before = "torch" in sys.modules and hasattr(sys.modules["torch"], "_bench_marker")
-        rc = bench.launch_ranks(args)
-    finally:
-        subprocess.run = real
-    assert rc == 0 and not before
-    cmd = seen["cmd"]
-    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
-    assert "127.0.0.1" in cmd and os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+    code = """
+import json, subprocess, sys
+sys.path.insert(0, %r)
+import bench
+seen = {}
+class R:
+    returncode = 0
+    stdout = '{"metric": "x", "n_gpus": 4}\\n'
+def fake_run(cmd, **kw):
+    seen["cmd"] = cmd
+    seen["env"] = kw.get("env", {}).get("HSA_ENABLE_IPC_MODE_LEGACY")
+    return R()
+subprocess.run = fake_run
+rc = bench.launch_ranks(type("A", (), {"gpus": 4})())
+assert rc == 0
+loaded = [m for m in ("torch", "cafexp_amd.capi", "numpy") if m in sys.modules]
+print(json.dumps({"cmd": seen["cmd"], "env": seen["env"], "loaded": loaded}))
+""" % ROOT
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-1500:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{") and "cmd" in ln][-1])
+    assert d["loaded"] == []                                  # nothing that could touch the GPU was even imported
+    cmd = d["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert "--standalone" in cmd and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1" and "--master-port" not in cmd
+    assert any(os.path.basename(c) == "bench.py" for c in cmd) and d["env"] == "0"
 
 
 def test_scaled_plan_moves_the_cuts_towards_the_shards_that_ran_long():

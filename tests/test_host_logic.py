@@ -151,7 +151,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.cafe_abi_version() == 2
+    assert lib.cafe_abi_version() == 3
 
 
 def test_product_does_not_touch_the_oracle():
