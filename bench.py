@@ -195,6 +195,26 @@ def other_configs(args):
         out[name] = {"families": pb.n_families, "ms_per_call": 1e3 * sec, "families_per_s": pb.n_families / sec, "neg_lnl": v,
                      "rel_err_vs_reference": abs(v - ref) / abs(ref), "reference_neg_lnl": ref}
     ctx.close()
+    def sample_parity(pb_, pr_, res_, n=64):
+        """The same full-size check the headline gets (`parity_sample`): n families spread over the table, pruned by the CPU
+        restatement, against the GPU's per-family values of this very call."""
+        import dataclasses
+        from oracle import oracle as O
+        O.set_threads(min(O.host_cpu_share(), args.cpu_threads or 10 ** 6))
+        sel = np.unique(np.linspace(0, pb_.n_families - 1, n).astype(np.int64))
+        sub = dataclasses.replace(pb_, counts=pb_.counts[sel].copy(), family_ids=[pb_.family_ids[i] for i in sel])
+        if pr_.multipliers is not None:
+            _, cat, fam = O.score_gamma(sub, pr_, fast=True, per_family=True)
+            rel = float(np.max(np.abs(res_["family_likelihood"][sel] / fam - 1.0)))
+            ok = cat > 0
+            rel = max(rel, float(np.max(np.abs(res_["category_likelihood"][sel][ok] / cat[ok] - 1.0))))
+        else:
+            _, fam = O.score_base(sub, pr_, fast=True, per_family=True)
+            rel = float(np.max(np.abs(res_["family_lnl"][sel] / fam - 1.0)))
+        return {"families_checked": int(len(sel)), "family_values_max_rel": rel, "tolerance": PARITY_TOL,
+                "against": "oracle/ CPU restatement, per-family values of the sampled families"}
+
+    check = not args.no_cpu_baseline
     # config 5: lambda tree with two rates + 3-tap error model, base model, 100 000 families (the bench's generator)
     pb5, _ = synth.make_problem(n_taxa=args.taxa, n_families=2 * args.families, max_count=args.max_count, lambda_clade_min=10, n_deviations=3)
     em = P.error_model_table(P.default_error_model(pb5.max_family_size)[:1] + [[0.05, 0.9, 0.05]], pb5.max_family_size)
@@ -202,22 +222,26 @@ def other_configs(args):
     ctx = capi.Context(pb5)
     ctx.set_profiling(False)
     sec, v = timed_calls(lambda: ctx.score(pr5), 3)
-    out["config5_shape_two_lambdas_error_model"] = {"families": pb5.n_families, "ms_per_call": 1e3 * sec, "families_per_s": pb5.n_families / sec,
-                                                    "neg_lnl": v, "rel_err_vs_reference": None}
+    out["config5_shape_two_lambdas_error_model"] = {"families": pb5.n_families, "ms_per_call": 1e3 * sec, "families_per_s": pb5.n_families / sec, "neg_lnl": v}
+    if check:
+        out["config5_shape_two_lambdas_error_model"]["parity_sample"] = sample_parity(pb5, pr5, ctx.family_results(0))
     ctx.close()
-    # SURVEY 8d's generator parameters for config 4 (lambda_sim 0.003, root sizes capped at 480; the headline uses 0.002 / 300):
-    # larger families, fewer shared subtree patterns, wider non-zero extents.  Scored at the headline's lambda / alpha
-    # (at 0.003 / 1.5 the reference itself returns +inf on 100-taxon families: unscaled fp64 likelihoods underflow).
+    # SURVEY 8d's generator parameters for config 4 (lambda_sim 0.003, root sizes capped at 480; the headline uses 0.002 / 300)
+    # scored at SURVEY 8d's point lambda 0.003 / alpha 1.5: larger families, fewer shared subtree patterns, wider non-zero
+    # extents.  (Finite: profiles/r03_zero_categories.json lists which (lambda, alpha) points have a zero category.)
     pb4, _ = synth.make_problem(n_taxa=args.taxa, n_families=args.families, max_count=args.max_count, lam_sim=0.003, root_cap=480)
     K = args.categories
-    probs, mult = discrete_gamma(K, args.alpha)
-    pr4 = P.Params(lambdas=np.array([args.lam]), prior=P.prior_uniform(pb4.max_root_family_size), multipliers=mult, cat_probs=probs)
-    ctx = capi.Context(pb4, max_categories=K)
-    ctx.set_profiling(False)
-    sec, v = timed_calls(lambda: ctx.score(pr4, alpha=args.alpha), 3)
-    out["config4_survey_generator_lambda_sim_0.003_root_cap_480"] = {"families": pb4.n_families, "ms_per_call": 1e3 * sec, "families_per_s": pb4.n_families / sec,
-                                                                     "neg_lnl": v, "rel_err_vs_reference": None}
-    ctx.close()
+    for key, lam, alpha in [("config4_survey_generator_lambda_sim_0.003_root_cap_480", args.lam, args.alpha),
+                            ("config4_survey_generator_and_scoring_point_lambda_0.003_alpha_1.5", 0.003, 1.5)]:
+        probs, mult = discrete_gamma(K, alpha)
+        pr4 = P.Params(lambdas=np.array([lam]), prior=P.prior_uniform(pb4.max_root_family_size), multipliers=mult, cat_probs=probs)
+        ctx = capi.Context(pb4, max_categories=K)
+        ctx.set_profiling(False)
+        sec, v = timed_calls(lambda: ctx.score(pr4, alpha=alpha), 3)
+        out[key] = {"families": pb4.n_families, "lambda": lam, "alpha": alpha, "ms_per_call": 1e3 * sec, "families_per_s": pb4.n_families / sec, "neg_lnl": v}
+        if check:
+            out[key]["parity_sample"] = sample_parity(pb4, pr4, ctx.family_results(K))
+        ctx.close()
     return out
 
 
@@ -499,7 +523,18 @@ def main():
                     cs.close()
                 out["two_streams_experimental"] = {"ms_per_step": 1e3 * two["2"][0], "one_stream_no_events_ms_per_step": 1e3 * two["1"][0],
                                                    "identical_to_headline": two["2"][1] == value and two["1"][1] == value}
+                for name in ("one_column_per_family", "every_k_tile", "two_streams_experimental"):
+                    if name in out and not out[name]["identical_to_headline"]:
+                        print("bench.py: %s is not bit-identical to the headline call: %r" % (name, out[name]), file=sys.stderr)
+                        rc = 3
                 out["other_configs"] = other_configs(args)
+                for name, leg in out["other_configs"].items():       # every -lnL this line prints is checked
+                    worst = leg.get("rel_err_vs_reference", leg.get("parity_sample", {}).get("family_values_max_rel", None))
+                    if worst is None and not args.no_cpu_baseline:
+                        worst = float("inf")
+                    if worst is not None and not worst <= PARITY_TOL:
+                        print("bench.py: PARITY FAILURE in other_configs[%s]: %r" % (name, leg), file=sys.stderr)
+                        rc = 3
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.barrier()
