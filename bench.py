@@ -60,8 +60,11 @@ def parse():
                     "communicator inside the library, all-reduce in cafe_score) on a one-GPU box")
     ap.add_argument("--shard-times", default="", help="with --emulate-shard: ms per shard measured under the default plan (comma list): "
                     "use the plan rebalanced by them, as the ranks of an N > 1 run do after their first calls")
-    ap.add_argument("--rebalance", action="store_true", help="N > 1: one step of measured rebalancing during set-up (every rank times a few "
-                    "calls of its predicted shard, the plan is corrected by the gathered times); rehearsed: largest shard 3.5 %% -> 3.1 %% above the mean")
+    ap.add_argument("--no-rebalance", dest="rebalance", action="store_false", help="N > 1: keep the predicted shard plan.  Default: one step "
+                    "of measured rebalancing during set-up (every rank times a few calls of its predicted shard, the plan is corrected by the "
+                    "gathered times)")
+    ap.add_argument("--rebalance", dest="rebalance", action="store_true", help="(the default)")
+    ap.set_defaults(rebalance=True)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI, issued by the library (the real thing); gloo: rehearsal of the N>1 path on a box "
                          "with fewer GPUs than ranks (all ranks share GPU 0, the pair is summed on the host)")
@@ -509,21 +512,23 @@ def main():
                                        "prune_gemm_tflops": ds["gemm_flops"] / (ds["ms_gemm"] * 1e-3) / 1e12 if ds["ms_gemm"] > 0 else None,
                                        "identical_to_headline": v == value}
                 dense.close()
-                # experimental, off by default: the root's second subtree on a second stream; no
-                # per-launch events (overlapping launches make them meaningless), so against the same call without events
-                two = {}
-                for n_streams in ("1", "2"):
-                    os.environ["CAFE_STREAMS"] = n_streams
+                # and with one op per launch (CAFE_NO_GROUPS: the post-order schedule of rounds 1-2, 98 K2 launches): what the
+                # level-batched launches buy; no per-launch events on either side
+                per_op = {}
+                for flag in ("0", "1"):
+                    if flag == "1":
+                        os.environ["CAFE_NO_GROUPS"] = "1"
                     try:
                         cs = capi.Context(pb, max_categories=max(1, K), device=device)
                     finally:
-                        del os.environ["CAFE_STREAMS"]
+                        os.environ.pop("CAFE_NO_GROUPS", None)
                     sec, v = timed_calls(lambda: cs.score(pr, alpha=args.alpha), 3)
-                    two[n_streams] = (sec, v)
+                    per_op[flag] = (sec, v, cs.stats()["gemm_launches"])
                     cs.close()
-                out["two_streams_experimental"] = {"ms_per_step": 1e3 * two["2"][0], "one_stream_no_events_ms_per_step": 1e3 * two["1"][0],
-                                                   "identical_to_headline": two["2"][1] == value and two["1"][1] == value}
-                for name in ("one_column_per_family", "every_k_tile", "two_streams_experimental"):
+                out["one_op_per_launch"] = {"ms_per_step": 1e3 * per_op["1"][0], "k2_launches": per_op["1"][2],
+                                            "grouped_no_events_ms_per_step": 1e3 * per_op["0"][0], "grouped_k2_launches": per_op["0"][2],
+                                            "identical_to_headline": per_op["1"][1] == value and per_op["0"][1] == value}
+                for name in ("one_column_per_family", "every_k_tile", "one_op_per_launch"):
                     if name in out and not out[name]["identical_to_headline"]:
                         print("bench.py: %s is not bit-identical to the headline call: %r" % (name, out[name]), file=sys.stderr)
                         rc = 3

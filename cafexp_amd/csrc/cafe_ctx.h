@@ -33,7 +33,44 @@ struct Op {
     bool has_gath;
     int gath_child;
     int gath_panel;
-    int stream;                 // 0, or 1: the op belongs to the subtree that may run on the second stream (CAFE_STREAMS=2)
+    int step;                   // ops of one step are mutually independent (see Group)
+    int desc;                   // index of the op's descriptor in the context's GemmOp / GatherArgs array
+};
+
+// A likelihood panel (or the transposed factor panel of a de-duplicated child): where it lives in the arena d_panels
+struct Panel {
+    int64_t cols = 0;           // columns (multiple of kBN)
+    bool factor = false;        // transposed factor: [category][column][factor_ld]; else [category][rows_pad][column]
+    int64_t offset = 0;         // doubles from d_panels
+    int64_t kstride = 0;        // doubles between categories
+    int first_step = 0, last_step = 0;   // written first / read last in these steps (arena planning)
+};
+
+// One launch: the ops of one step that share a kernel variant.  Steps come from the dependency graph of the ops (an op
+// reads the panels of its children and, when it multiplies, what an earlier op left in its own): all ops of a step are
+// independent, so a step is a level of ready nodes (one launch per height; reference loop core.cpp:133-144).
+struct Group {
+    int type = 0;               // 1: K2 (prune_gemm), 0: K3 (leaf gather / assemble)
+    int step = 0;
+    std::vector<int> ops;       // indices into cafe_ctx::ops, descriptors contiguous from first_desc
+    int first_desc = 0;
+    GemmVariant variant{0, 0, 0};
+    bool to_root = false;
+};
+
+// What a call's launches need beyond the static descriptors, per (reduction, K): tile heights, tile lists.  The context
+// has one for the stream path (uploaded when it changes) and every captured graph one of its own.
+struct DescSet {
+    GemmOp* d_gemm_ops = nullptr;
+    PlanLaunch* d_plan_desc = nullptr;
+    int2* d_plan = nullptr;
+    std::vector<GemmOp> gemm_ops_sent;
+    std::vector<PlanLaunch> plan_desc_sent;
+    std::vector<int> group_mi, group_blocks, group_rounds;     // per K2 group (index = position among the K2 groups)
+    std::vector<size_t> group_plan_off;
+    bool plan_static_valid = false;          // no extents: the lists depend on (K, tile heights, chunk width) only
+    int plan_static_K = 0;
+    int64_t plan_static_cols = 0;
 };
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -54,6 +91,16 @@ struct cafe_ctx {
 
     // schedule
     std::vector<cafe::Op> ops;
+    std::vector<cafe::Panel> panels;         // by panel id (Op::dst_panel, ...)
+    std::vector<cafe::Group> groups;         // launch order
+    bool grouped = false;                    // one column chunk: every panel has its own place, steps hold many ops
+    int n_gemm_ops = 0, n_gather_ops = 0, n_gemm_groups = 0;
+    std::vector<cafe::GemmOp> h_gemm_ops;    // static part of the K2 descriptors (n_row_tiles is filled per call)
+    std::vector<cafe::GatherArgs> h_gather_ops;
+    cafe::GatherArgs* d_gather_ops = nullptr;
+    cafe::GemmOp* h_gemm_stage = nullptr;    // pinned
+    cafe::DescSet desc;                      // stream path
+    bool panels_dirty = false;               // the last call returned NaN: stale NaNs may sit in padding rows; cleared before the next call
     // subtree-level de-duplication: a node's panel has one column per distinct pattern of leaf counts UNDER that node
     bool subtree_dedup = false;
     std::vector<int64_t> pat_cols;           // [n_nodes] padded distinct patterns of an interior node (0 for leaves)
@@ -135,6 +182,7 @@ struct cafe_ctx {
     struct CallGraph {
         hipGraphExec_t exec = nullptr;
         cafe_stats stats{};                  // the work counters of the captured sequence
+        cafe::DescSet desc;                  // its own descriptors and tile lists (frozen at capture)
     };
     std::map<int, CallGraph> graphs;
     int use_graph = 0;
@@ -155,26 +203,17 @@ struct cafe_ctx {
     int32_t* h_ext = nullptr;                // pinned [max_kslots][ext_blocks][2]
     // tile lists of the K2 launches (tile_plan_kernel): one descriptor per launch, rebuilt per call (the tile heights may
     // change), uploaded when it differs from the last upload
-    // experimental (CAFE_STREAMS=2 at cafe_create): the second interior subtree under the root gets its own panels and runs on
-    // a second stream, forked behind K1 / extents / planner and joined in front of the root's launches
-    int n_streams = 1;
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    void* side_alloc = nullptr;              // PanelAlloc of the side subtree while the schedule is emitted
-    bool use_plan = false;
-    int plan_launches_last = 0;              // K2 launches of the last recorded call that ran from planned lists
+    int plan_launches_last = 0;              // K2 launches of the last recorded call
     int plan_bias = 8;                       // percent by which the first-dispatched workgroup of a CU outruns the other (measured; CAFE_PLAN_BIAS)
     int plan_fixed = 4;                      // cost of an output tile beyond its K loop, in K tiles (fitted: DESIGN.md; CAFE_PLAN_FIXED)
-    int2* d_plan = nullptr;
     size_t plan_entries = 0;
-    cafe::PlanLaunch* d_plan_desc = nullptr;
     cafe::PlanLaunch* h_plan_desc = nullptr;        // pinned
-    std::vector<cafe::PlanLaunch> plan_desc_sent;
+    const cafe::DescSet* desc_last = nullptr;       // descriptors of the last recorded call (diagnostics)
     bool h_ext_valid = false;
     int h_ext_K = 0;                         // categories of the call the copy belongs to
 
     // measurement
-    struct GemmLaunch { int child; int rows; int64_t cols; int K; int mi; };   // what collect_stats needs to count executed flops
+    struct GemmLaunch { int group; int K; int mi; int64_t cols; };   // what count_executed_flops needs (cols: the chunk's, several chunks only)
     std::vector<GemmLaunch> gemm_launches_info;
     bool stats_flops_stale = false;           // gemm_flops still holds the dense count of the last profiled call
     int profile = 0;

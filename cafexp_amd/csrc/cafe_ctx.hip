@@ -56,42 +56,23 @@ int panel_need(const cafe_ctx* c, int v, std::vector<int>& need) {
 }
 
 struct PanelAlloc {
+    bool reuse = true;          // false: every panel gets an id of its own (grouped schedule; the arena is planned afterwards)
     std::vector<int> free_list;
     int high = 0;
     int get() {
-        if (!free_list.empty()) { int p = free_list.back(); free_list.pop_back(); return p; }
+        if (reuse && !free_list.empty()) { int p = free_list.back(); free_list.pop_back(); return p; }
         return high++;
     }
-    void put(int p) { free_list.push_back(p); }
+    void put(int p) { if (reuse) free_list.push_back(p); }
 };
 
-constexpr int kSideBase = 1 << 20;
 int emit_node(cafe_ctx* c, int v, const std::vector<int>& need, PanelAlloc& pa) {
     std::vector<int> inner, leaves;
     for (int u : c->children[v]) (c->leaf_taxon[u] < 0 ? inner : leaves).push_back(u);
     std::vector<int> order = inner;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return need[x] > need[y]; });
     std::map<int, int> panel_of;
-    for (size_t idx = 0; idx < order.size(); ++idx) {
-        const int u = order[idx];
-        if (v == c->root && c->side_alloc && order.size() >= 2 && idx == 1) {
-            // the root's second interior subtree: panels of its own (ids from kSideBase, renumbered behind the main pool
-            // once that is complete), every launch tagged for the second stream
-            const size_t first = c->ops.size();
-            const int p = emit_node(c, u, need, *static_cast<PanelAlloc*>(c->side_alloc));
-            for (size_t i = first; i < c->ops.size(); ++i) {
-                Op& o = c->ops[i];
-                o.stream = 1;
-                o.dst_panel += kSideBase;
-                if (o.type == 1) o.src_panel += kSideBase;
-                for (int j = 0; j < o.n_src; ++j) o.src_panels[j] += kSideBase;
-                if (o.has_gath) o.gath_panel += kSideBase;
-            }
-            panel_of[u] = p + kSideBase;
-        } else {
-            panel_of[u] = emit_node(c, u, need, pa);
-        }
-    }
+    for (size_t idx = 0; idx < order.size(); ++idx) panel_of[order[idx]] = emit_node(c, order[idx], need, pa);
     const int dst = pa.get();
     bool init = false;
     // A parent with interior children folds (up to kMaxLeafPerOp of) its leaf children into the epilogue of
@@ -318,7 +299,6 @@ void free_device(cafe_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     comm_release(c);
     for (auto& g : c->graphs) if (g.second.exec) hipGraphExecDestroy(g.second.exec);
-    c->graphs.clear();
     hipFree(c->d_counts); hipFree(c->d_weights); hipFree(c->pool.base); hipFree(c->kpool.base); hipFree(c->kpool.ext); hipFree(c->pool.ext); hipFree(c->d_params); hipFree(c->d_panels);
     hipFree(c->d_ext_nodes);
     for (auto ptr : c->d_colext) hipFree(ptr);
@@ -330,14 +310,16 @@ void free_device(cafe_ctx* c) {
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_result) hipHostFree(c->h_result);
     if (c->h_ext) hipHostFree(c->h_ext);
-    hipFree(c->d_plan); hipFree(c->d_plan_desc);
+    auto free_desc = [](DescSet& d) { hipFree(d.d_gemm_ops); hipFree(d.d_plan_desc); hipFree(d.d_plan); d = DescSet(); };
+    free_desc(c->desc);
+    for (auto& g : c->graphs) free_desc(g.second.desc);
+    hipFree(c->d_gather_ops);
+    if (c->h_gemm_stage) hipHostFree(c->h_gemm_stage);
     if (c->h_plan_desc) hipHostFree(c->h_plan_desc);
     if (c->ev_upload) hipEventDestroy(c->ev_upload);
     for (auto& e : c->ev) if (e) hipEventDestroy(e);
     for (auto& e : c->gemm_ev) hipEventDestroy(e);
-    if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
-    if (c->ev_fork) hipEventDestroy(c->ev_fork);
-    if (c->ev_join) hipEventDestroy(c->ev_join);
+    c->graphs.clear();
     if (c->stream) hipStreamDestroy(c->stream);
 }
 
@@ -443,9 +425,6 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     HIP_TRY(c, hipSetDevice(c->device));
     c->device_ready = true;
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
 
     // counts, taxon-major, padded families replicate an all-zero family
     {
@@ -460,26 +439,11 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
         HIP_TRY(c, hipMemcpy(c->d_weights, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
     }
 
-    // subtree-level de-duplication tables, then the schedule (which depends on them)
+    // subtree-level de-duplication tables (the schedule depends on them)
     c->subtree_dedup = !device_counts && !(p->flags & CAFE_FLAG_NO_SUBTREE_DEDUP);
     if (c->subtree_dedup) { const int rc = compute_patterns(c, p, uniq); if (rc != CAFE_OK) return rc; }
     std::vector<int> need(c->n_nodes, 0);
     panel_need(c, c->root, need);
-    if (const char* e = std::getenv("CAFE_STREAMS")) c->n_streams = atoi(e) == 2 ? 2 : 1;
-    {
-        PanelAlloc pa, side;
-        c->side_alloc = c->n_streams == 2 ? &side : nullptr;
-        c->root_panel = emit_node(c, c->root, need, pa);
-        c->side_alloc = nullptr;
-        auto fix = [&](int& id) { if (id >= kSideBase) id = pa.high + (id - kSideBase); };
-        for (Op& o : c->ops) {
-            fix(o.dst_panel);
-            if (o.type == 1) fix(o.src_panel);
-            for (int j = 0; j < o.n_src; ++j) fix(o.src_panels[j]);
-            if (o.has_gath) fix(o.gath_panel);
-        }
-        c->n_panels = pa.high + side.high;
-    }
 
     // matrix pools: one slot per (distinct quantized branch length, lambda index) pair and category, per layout.
     // Leaf branches use row-major matrices (K3 gathers a column), interior branches k-major ones (K2's A).
@@ -610,28 +574,137 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     size_t free_b = 0, total_b = 0;
     HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
     c->workspace_limit = p->workspace_limit;
-    size_t budget = p->workspace_limit ? p->workspace_limit : (size_t)(free_b * 0.80);
-    const size_t per_col = (size_t)c->n_panels * c->Kmax * c->rows_pad * sizeof(double);
-    int64_t cols = (int64_t)(budget / per_col) / kBN * kBN;
+    const size_t budget = p->workspace_limit ? p->workspace_limit : (size_t)(free_b * 0.80);
     // K2 addresses a panel category through a 32-bit buffer descriptor: rows_pad * cols * 8 bytes must stay below 4 GB
-    cols = std::min<int64_t>(cols, (int64_t)(0xFFFFFFF0ll / ((int64_t)c->rows_pad * 8)) / kBN * kBN);
-    if (cols < kBN) { set_err(c, "cafe_create: %zu bytes of workspace cannot hold %d panels of one 128-family tile", budget, c->n_panels); return CAFE_ERR_MEMORY; }
-    c->chunk_cols = std::min<int64_t>(cols, c->Fp);
-    if (c->subtree_dedup && c->chunk_cols < c->Fp) {
-        // several column chunks: the per-node column maps address whole panels, so this case keeps one column per
-        // family in every panel (the schedule without combine passes needs no more panels than the one with them)
-        c->subtree_dedup = false;
-        c->panel_extents = false;
-        c->ops.clear();
-        c->n_streams = 1;
+    const int64_t desc_cols = (int64_t)(0xFFFFFFF0ll / ((int64_t)c->rows_pad * 8)) / kBN * kBN;
+
+    // ---- the schedule.  Preferred (the table fits one column chunk with a place of its own for every panel): GROUPED --
+    // the ops are levelled by their dependencies into steps, a step's ops of one kernel variant share a launch, and the
+    // arena is planned from the panels' lifetimes.  Otherwise: one op per launch in post-order with the Sethi-Ullman slot
+    // pool (few live panels), in as many column chunks as the workspace asks for.
+    auto cols_of = [&](int v) -> int64_t { return c->subtree_dedup ? c->pat_cols[v] : c->Fp; };
+    size_t panel_doubles = 0;
+    c->grouped = !std::getenv("CAFE_NO_GROUPS");
+    if (c->grouped) {
         PanelAlloc pa;
+        pa.reuse = false;
+        c->ops.clear();
+        c->root_panel = emit_node(c, c->root, need, pa);
+        c->panels.assign(pa.high, Panel());
+        // what each panel is: the transposed factor of a child (its own columns) or a node's panel
+        for (const Op& op : c->ops) {
+            Panel& P = c->panels[op.dst_panel];
+            P.factor = op.type == 1 && op.to_factor;
+            P.cols = P.factor ? cols_of(op.child) : cols_of(op.parent);
+            P.kstride = P.cols * (P.factor ? c->factor_ld : c->rows_pad);
+        }
+        // steps: an op runs one step after the last op it depends on -- the writers of what it reads (its children's panels,
+        // gathered factors, and its own destination when it multiplies)
+        {
+            std::vector<int> last_writer(c->panels.size(), -1);
+            int n_steps = 0;
+            for (size_t i = 0; i < c->ops.size(); ++i) {
+                Op& op = c->ops[i];
+                int st = 0;
+                auto dep = [&](int panel) { if (last_writer[panel] >= 0) st = std::max(st, c->ops[last_writer[panel]].step + 1); };
+                if (op.type == 1) { dep(op.src_panel); if (op.has_gath) dep(op.gath_panel); }
+                for (int j = 0; j < op.n_src; ++j) dep(op.src_panels[j]);
+                dep(op.dst_panel);                           // (a store is the first writer: no-op; a multiply follows the store)
+                op.step = st;
+                last_writer[op.dst_panel] = (int)i;
+                n_steps = std::max(n_steps, st + 1);
+            }
+            for (Panel& P : c->panels) { P.first_step = 0x7fffffff; P.last_step = -1; }
+            for (const Op& op : c->ops) {
+                auto use = [&](int panel) { Panel& P = c->panels[panel]; P.first_step = std::min(P.first_step, op.step); P.last_step = std::max(P.last_step, op.step); };
+                use(op.dst_panel);
+                if (op.type == 1) { use(op.src_panel); if (op.has_gath) use(op.gath_panel); }
+                for (int j = 0; j < op.n_src; ++j) use(op.src_panels[j]);
+            }
+            c->panels[c->root_panel].last_step = n_steps;    // K4 and cafe_get_root_likelihoods read it after the last step
+            // arena: first fit over the steps; a panel's place is free again after the step that reads it last
+            std::vector<std::pair<int64_t, int64_t>> holes;  // (offset, length) sorted by offset
+            int64_t top = 0;
+            std::vector<std::vector<int>> born(n_steps + 1), dies(n_steps + 1);
+            for (size_t i = 0; i < c->panels.size(); ++i) { born[c->panels[i].first_step].push_back((int)i); dies[c->panels[i].last_step].push_back((int)i); }
+            for (int st = 0; st <= n_steps; ++st) {
+                std::sort(born[st].begin(), born[st].end(), [&](int x, int y) { return c->panels[x].kstride > c->panels[y].kstride; });
+                for (int id : born[st]) {
+                    Panel& P = c->panels[id];
+                    const int64_t len = round_up64(P.kstride * c->Kmax, 64);          // 512-byte granules
+                    bool placed = false;
+                    for (size_t h = 0; h < holes.size() && !placed; ++h)
+                        if (holes[h].second >= len) {
+                            P.offset = holes[h].first;
+                            holes[h].first += len; holes[h].second -= len;
+                            if (holes[h].second == 0) holes.erase(holes.begin() + h);
+                            placed = true;
+                        }
+                    if (!placed) {
+                        if (!holes.empty() && holes.back().first + holes.back().second == top) {     // grow the hole at the top
+                            P.offset = holes.back().first;
+                            top = P.offset + len;
+                            holes.pop_back();
+                        } else {
+                            P.offset = top;
+                            top += len;
+                        }
+                    }
+                }
+                for (int id : dies[st]) {
+                    const Panel& P = c->panels[id];
+                    const int64_t len = round_up64(P.kstride * c->Kmax, 64);
+                    auto it = std::lower_bound(holes.begin(), holes.end(), std::make_pair(P.offset, (int64_t)0));
+                    it = holes.insert(it, std::make_pair(P.offset, len));
+                    if (it + 1 != holes.end() && it->first + it->second == (it + 1)->first) { it->second += (it + 1)->second; holes.erase(it + 1); }
+                    if (it != holes.begin() && (it - 1)->first + (it - 1)->second == it->first) { (it - 1)->second += it->second; holes.erase(it); }
+                }
+            }
+            panel_doubles = (size_t)top;
+        }
+        int64_t widest = 0;
+        for (const Panel& P : c->panels) widest = std::max(widest, P.cols);
+        // (a place of its own for every panel takes several times the slot pool: not when that is more than half the workspace)
+        if (panel_doubles * sizeof(double) + 65536 > budget / 2 || widest > desc_cols) c->grouped = false;
+    }
+    if (c->grouped) {
+        c->chunk_cols = c->Fp;
+        c->n_panels = (int)c->panels.size();
+        c->panel_kstride = (int64_t)c->rows_pad * c->Fp;     // (the root panel's, what K4 reads)
+        c->panel_stride = 0;
+    } else {
+        PanelAlloc pa;
+        c->ops.clear();
         c->root_panel = emit_node(c, c->root, need, pa);
         c->n_panels = pa.high;
+        size_t per_col = (size_t)c->n_panels * c->Kmax * c->rows_pad * sizeof(double);
+        int64_t cols = std::min<int64_t>((int64_t)(budget / per_col) / kBN * kBN, desc_cols);
+        if (c->subtree_dedup && cols < c->Fp) {
+            // several column chunks: the per-node column maps address whole panels, so this case keeps one column per
+            // family in every panel (the schedule without combine passes needs no more panels than the one with them)
+            c->subtree_dedup = false;
+            c->ops.clear();
+            PanelAlloc pb;
+            c->root_panel = emit_node(c, c->root, need, pb);
+            c->n_panels = pb.high;
+            per_col = (size_t)c->n_panels * c->Kmax * c->rows_pad * sizeof(double);
+            cols = std::min<int64_t>((int64_t)(budget / per_col) / kBN * kBN, desc_cols);
+        }
+        if (cols < kBN) { set_err(c, "cafe_create: %zu bytes of workspace cannot hold %d panels of one 128-family tile", budget, c->n_panels); return CAFE_ERR_MEMORY; }
+        c->chunk_cols = std::min<int64_t>(cols, c->Fp);
+        c->panel_kstride = (int64_t)c->rows_pad * c->chunk_cols;
+        c->panel_stride = c->panel_kstride * c->Kmax;
+        c->panels.assign(c->n_panels, Panel());
+        for (int i = 0; i < c->n_panels; ++i) {              // slots as wide as the widest panel; a node uses a prefix with its own leading dimension
+            c->panels[i].cols = c->chunk_cols;
+            c->panels[i].offset = (int64_t)i * c->panel_stride;
+            c->panels[i].kstride = c->panel_kstride;
+        }
+        for (size_t i = 0; i < c->ops.size(); ++i) c->ops[i].step = (int)i;
+        panel_doubles = (size_t)c->n_panels * c->panel_stride;
     }
-    c->panel_kstride = (int64_t)c->rows_pad * c->chunk_cols;
-    c->panel_stride = c->panel_kstride * c->Kmax;
     // (+64 KB: the assemble pass reads whole 64-row tiles of a transposed factor, up to a tile past its last column)
-    const size_t panel_bytes = (size_t)c->n_panels * c->panel_stride * sizeof(double) + 65536;
+    const size_t panel_bytes = panel_doubles * sizeof(double) + 65536;
     if (hipMalloc(&c->d_panels, panel_bytes) != hipSuccess) {
         set_err(c, "cafe_create: cannot allocate %.2f GB of likelihood panels", panel_bytes / 1e9);
         return CAFE_ERR_MEMORY;
@@ -701,49 +774,141 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     }
 
 
-    // tile lists for the K2 launches: room for the tallest list any tile height can ask for
-    // (the planner is one 64-lane wave per XCD, a lane per workgroup: MI355X has 32 CUs x 2 workgroups per XCD)
-    c->use_plan = c->kpool.ext && c->stats.n_chunks == 1 && 2 * c->n_cu / 8 <= 64 && !std::getenv("CAFE_NO_PLAN");
+    // ---- launches: the ops of a step that share a kernel variant go out together
     if (const char* e = std::getenv("CAFE_PLAN_FIXED")) c->plan_fixed = std::max(0, atoi(e));
     if (const char* e = std::getenv("CAFE_PLAN_BIAS")) c->plan_bias = std::min(50, std::max(0, atoi(e)));
-    if (c->use_plan) {
-        size_t entries = 0, n_gemm = 0;
-        for (const Op& op : c->ops) {
-            if (op.type != 1) continue;
-            ++n_gemm;
-            const int64_t gc = c->subtree_dedup ? c->pat_cols[op.child] : c->chunk_cols;
-            const int rows = op.to_root ? c->R : c->M;
+    {
+        std::vector<size_t> idx(c->ops.size());
+        for (size_t i = 0; i < idx.size(); ++i) idx[i] = i;
+        auto key = [&](const Op& o) -> int {                 // launch order inside a step: factor GEMMs, the other GEMMs, then K3
+            if (o.type == 1) return o.to_factor ? 0 : 1 + (o.has_gath ? 2 : (o.n_leaf ? 1 : 0)) * 2 + o.mode;
+            return 16 + o.n_src * 32 + o.n_leaf * 2 + o.mode;
+        };
+        std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) {
+            const Op &a = c->ops[x], &b = c->ops[y];
+            if (a.step != b.step) return a.step < b.step;
+            if (a.to_root != b.to_root) return b.to_root;
+            return key(a) < key(b);
+        });
+        for (size_t i : idx) {
+            Op& o = c->ops[i];
+            const bool fresh = c->groups.empty() || c->groups.back().step != o.step || c->groups.back().type != o.type ||
+                               key(c->ops[c->groups.back().ops[0]]) != key(o) || c->groups.back().to_root != o.to_root ||
+                               (int)c->groups.back().ops.size() >= (o.type == 1 ? kMaxGroupOps : 512);
+            if (fresh) {
+                Group g;
+                g.type = o.type; g.step = o.step; g.to_root = o.to_root;
+                g.first_desc = o.type == 1 ? c->n_gemm_ops : c->n_gather_ops;
+                if (o.type == 1) g.variant = GemmVariant{o.mode, o.has_gath ? 2 : (o.n_leaf ? 1 : 0), o.to_factor ? 1 : 0};
+                c->groups.push_back(g);
+                c->n_gemm_groups += o.type == 1;
+            }
+            o.desc = o.type == 1 ? c->n_gemm_ops++ : c->n_gather_ops++;
+            c->groups.back().ops.push_back((int)i);
+        }
+    }
+    // static descriptors (n_row_tiles of a K2 op follows the tile height, chosen per call)
+    c->h_gemm_ops.assign(std::max(1, c->n_gemm_ops), GemmOp{});
+    c->h_gather_ops.assign(std::max(1, c->n_gather_ops), GatherArgs{});
+    for (const Op& op : c->ops) {
+        const int32_t* cnt_base = c->subtree_dedup ? c->d_leaf_cnt[op.parent] : c->d_counts;
+        const int64_t cnt_ld = c->subtree_dedup ? c->pat_cols[op.parent] : c->Fp;
+        auto cnt_row = [&](int leaf) { return c->subtree_dedup ? c->leaf_rank[leaf] : c->leaf_taxon[leaf]; };
+        const Panel& D = c->panels[op.dst_panel];
+        if (op.type == 1) {
+            GemmOp& g = c->h_gemm_ops[op.desc];
+            const Panel& S = c->panels[op.src_panel];
+            for (int k = 0; k < c->Kmax; ++k) g.slot[k] = c->slot_of[(size_t)op.child * c->Kmax + k];
+            g.src = c->d_panels + S.offset; g.src_kstride = S.kstride;
+            g.dst = c->d_panels + D.offset; g.dst_kstride = D.kstride;
+            g.ld = (int32_t)cols_of(op.child);               // the GEMM runs over the child's columns (= the parent's when direct)
+            g.n_col_tiles = g.ld / kBN;
+            g.rows = op.to_root ? c->R : c->M;               // parent sizes 1..rows
+            g.out_off = op.to_root ? 0 : 1;
+            g.dst_ldt = op.to_factor ? c->factor_ld : 0;
+            g.n_leaf = op.n_leaf;
+            if (op.n_leaf) {
+                g.taxon = cnt_row(op.leaf_node[0]);
+                for (int k = 0; k < c->Kmax; ++k) g.leaf_slot[k] = c->slot_of[(size_t)op.leaf_node[0] * c->Kmax + k];
+            }
+            g.counts = cnt_base; g.counts_ld = cnt_ld;
+            if (op.has_gath) {
+                const Panel& G = c->panels[op.gath_panel];
+                g.gath_src = c->d_panels + G.offset; g.gath_kstride = G.kstride;
+                g.gath_ld = c->factor_ld;
+                g.gath_map = c->d_edge_map[op.gath_child];
+            }
+            g.bext = c->panel_extents ? c->d_tileext[op.child] : nullptr;
+        } else {
+            GatherArgs& g = c->h_gather_ops[op.desc];
+            g.n_leaf = op.n_leaf;
+            for (int l = 0; l < op.n_leaf; ++l) {
+                g.taxon[l] = cnt_row(op.leaf_node[l]);
+                for (int k = 0; k < c->Kmax; ++k) g.slot[l][k] = c->slot_of[(size_t)op.leaf_node[l] * c->Kmax + k];
+            }
+            g.counts = cnt_base; g.counts_ld = cnt_ld;
+            g.dst = c->d_panels + D.offset; g.panel_kstride = D.kstride; g.ld = (int32_t)cols_of(op.parent);
+            g.row_off = op.to_root ? 1 : 0;
+            g.rows = op.to_root ? c->R : c->M + 1;
+            g.rows_store = op.to_root ? c->R : c->kc;
+            g.mode = op.mode;
+            g.n_src = op.n_src;
+            for (int j = 0; j < op.n_src; ++j) {
+                const Panel& S = c->panels[op.src_panels[j]];
+                g.src[j] = c->d_panels + S.offset; g.kstride_src[j] = S.kstride;
+                g.ld_src[j] = c->factor_ld;
+                g.map[j] = c->d_edge_map[op.src_child[j]];
+            }
+            // (the root's vector is read whole by the reduction and has no extent record)
+            g.tileext = c->panel_extents && !op.to_root && !c->no_asm_skip ? c->d_tileext[op.parent] : nullptr;
+        }
+    }
+    HIP_TRY(c, hipMalloc(&c->d_gather_ops, sizeof(GatherArgs) * c->h_gather_ops.size()));
+    HIP_TRY(c, hipMemcpy(c->d_gather_ops, c->h_gather_ops.data(), sizeof(GatherArgs) * c->h_gather_ops.size(), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipHostMalloc(&c->h_gemm_stage, sizeof(GemmOp) * c->h_gemm_ops.size(), hipHostMallocDefault));
+    // tile lists of the K2 launches: room for the tallest list any tile height can ask for
+    // (the planner is one 64-lane wave per XCD, a lane per workgroup: MI355X has 32 CUs x 2 workgroups per XCD)
+    {
+        size_t entries = 0;
+        for (const Group& g : c->groups) {
+            if (g.type != 1) continue;
             size_t worst = 0;
             for (int mi = 4; mi <= 9; ++mi) {
-                const int nrt = (rows + 16 * mi - 1) / (16 * mi), nct = (int)(gc / kBN);
-                const int nlb = prune_gemm_blocks(c->Kmax, nct, nrt, c->n_cu) / 8;
-                const int64_t tiles = (((int64_t)c->Kmax * nct + 7) / 8) * nrt;
-                (void)nlb;
+                int64_t tiles = 0;
+                for (int oi : g.ops) {
+                    const Op& op = c->ops[oi];
+                    const int rows = op.to_root ? c->R : c->M;
+                    const int64_t gc = c->subtree_dedup ? c->pat_cols[op.child] : c->chunk_cols;
+                    tiles += prune_gemm_tiles_xcd0(c->Kmax, (int)(gc / kBN), (rows + 16 * mi - 1) / (16 * mi));
+                }
                 worst = std::max(worst, (size_t)8 * (size_t)(tiles + 64 * (1 + kPlanSlack)));   // >= 8 * nlb * (ceil(tiles / nlb) + slack), any K <= Kmax
             }
             entries += worst;
         }
         c->plan_entries = entries;
-        HIP_TRY(c, hipMalloc(&c->d_plan, sizeof(int2) * std::max<size_t>(1, entries)));
-        HIP_TRY(c, hipMalloc(&c->d_plan_desc, sizeof(PlanLaunch) * std::max<size_t>(1, n_gemm)));
-        HIP_TRY(c, hipHostMalloc(&c->h_plan_desc, sizeof(PlanLaunch) * std::max<size_t>(1, n_gemm), hipHostMallocDefault));
+        HIP_TRY(c, hipHostMalloc(&c->h_plan_desc, sizeof(PlanLaunch) * std::max(1, c->n_gemm_groups), hipHostMallocDefault));
     }
 
     if (std::getenv("CAFE_DUMP_SCHEDULE")) {             // diagnostic: the launch list with its column counts
-        for (auto& op : c->ops) {
-            const int64_t pc = c->subtree_dedup ? c->pat_cols[op.parent] : c->chunk_cols;
-            if (op.type == 1)
-                std::fprintf(stderr, "cafe schedule: gemm child %d -> parent %d cols %lld %s%s%s leaf %d\n", op.child, op.parent,
-                             (long long)(c->subtree_dedup ? c->pat_cols[op.child] : c->chunk_cols), op.to_factor ? "factor(transposed)" : (op.mode ? "multiply" : "store"),
-                             op.has_gath ? " +gathered-factor" : "", op.to_root ? " root" : "", op.n_leaf);
-            else
-                std::fprintf(stderr, "cafe schedule: %s parent %d cols %lld factors %d leaves %d %s\n", op.n_src ? "assemble" : "leaf-gather", op.parent,
-                             (long long)pc, op.n_src, op.n_leaf, op.mode ? "multiply" : "store");
+        std::fprintf(stderr, "cafe schedule: %s, %zu ops in %zu launches, %d panels, %.2f GB\n", c->grouped ? "grouped" : "one op per launch", c->ops.size(),
+                     c->groups.size(), c->n_panels, c->stats.panel_bytes / 1e9);
+        for (const Group& g : c->groups) {
+            std::fprintf(stderr, "cafe schedule: step %d %s x%zu\n", g.step, g.type == 1 ? "K2" : "K3", g.ops.size());
+            for (int oi : g.ops) {
+                const Op& op = c->ops[oi];
+                const int64_t pc = c->subtree_dedup ? c->pat_cols[op.parent] : c->chunk_cols;
+                if (op.type == 1)
+                    std::fprintf(stderr, "cafe schedule:   gemm child %d -> parent %d cols %lld %s%s%s leaf %d\n", op.child, op.parent,
+                                 (long long)(c->subtree_dedup ? c->pat_cols[op.child] : c->chunk_cols), op.to_factor ? "factor(transposed)" : (op.mode ? "multiply" : "store"),
+                                 op.has_gath ? " +gathered-factor" : "", op.to_root ? " root" : "", op.n_leaf);
+                else
+                    std::fprintf(stderr, "cafe schedule:   %s parent %d cols %lld factors %d leaves %d %s\n", op.n_src ? "assemble" : "leaf-gather", op.parent,
+                                 (long long)pc, op.n_src, op.n_leaf, op.mode ? "multiply" : "store");
+            }
         }
     }
-    int n_gemm = 0;
+    int n_gemm = c->n_gemm_groups;
     for (auto& op : c->ops) {
-        n_gemm += op.type == 1;
         c->stats.n_gather_epilogues += op.type == 1 && op.has_gath;
         c->stats.n_assemble_passes += op.type == 0 && op.n_src > 0;
         c->stats.n_leaf_passes += op.type == 0 && op.n_src == 0;
@@ -828,12 +993,12 @@ bool rejected(const cafe_ctx* c, const cafe_params* pr, int K) {
     return (1 - 2 * alpha) < 0;
 }
 
-// Row-tile height of one K2 launch from the (previous call's) non-zero extents of its matrices: a tile runs only the K
-// tiles inside the union of its 16-row blocks' extents, so a lower tile hugs the band of a short branch more closely (at
-// config 4 the launches execute 69 % of all K tiles with 144-row tiles, 64 % with 80-row ones) but is a little less
-// efficient per MFMA and fills the persistent grid in different rounds.  Costs in units of one K tile of one 16-row block;
-// the efficiency factors are measured (forced tile heights): even heights stage a padded A tile.
-int pick_tile_height(const cafe_ctx* c, const int32_t* ext, int child, int rows, int n_col_tiles, int K) {
+// Row-tile height of one K2 launch (a group of ops) from the (previous call's) non-zero extents of its matrices: a tile runs
+// only the K tiles inside the union of its 16-row blocks' extents, so a lower tile hugs the band of a short branch more
+// closely (at config 4 the launches execute 69 % of all K tiles with 144-row tiles, 64 % with 80-row ones) but is a little
+// less efficient per MFMA and fills the persistent grid in different rounds.  Costs in units of one K tile of one 16-row
+// block; the efficiency factors are measured (forced tile heights): even heights stage a padded A tile.
+int pick_tile_height(const cafe_ctx* c, const int32_t* ext, const Group& g, int K, int64_t chunk_cols) {
     static const double eff[10] = {0, 0, 0, 0, 1.12, 1.03, 1.30, 1.06, 1.05, 1.00};
     const int nb = c->kpool.ext_blocks, slots = 2 * c->n_cu / 8 * 8;
     const int n_k = (c->M + 1 + kBK - 1) / kBK;
@@ -842,33 +1007,137 @@ int pick_tile_height(const cafe_ctx* c, const int32_t* ext, int child, int rows,
     double best_cost = 1e300;
     for (int mi = 9; mi >= 4; --mi) {
         if (mi == 6) continue;
-        const int row_tiles = (rows + 16 * mi - 1) / (16 * mi);
-        double work = 0;                     // sum over (category, row tile) of (K tiles + overhead) * height
-        for (int k = 0; k < K; ++k) {
-            const int32_t* e = ext + (size_t)c->slot_of[(size_t)child * c->Kmax + k] * nb * 2;
-            for (int rt = 0; rt < row_tiles; ++rt) {
-                int lo = 0x7fffffff, hi = -1;
-                for (int b = rt * mi; b < rt * mi + mi && b < nb; ++b) { lo = std::min(lo, e[2 * b]); hi = std::max(hi, e[2 * b + 1]); }
-                int nkt = n_k;
-                if (hi >= lo) nkt = std::min(hi, c->M) / kBK - lo / kBK + 1; else nkt = 1;
-                work += (nkt + overhead) * mi;
+        double work = 0, tiles = 0;          // sum over (op, category, row tile, column tile) of (K tiles + overhead) * height; tiles
+        for (int oi : g.ops) {
+            const Op& op = c->ops[oi];
+            const int rows = op.to_root ? c->R : c->M;
+            const int n_col_tiles = (int)((c->subtree_dedup ? c->pat_cols[op.child] : chunk_cols) / kBN);
+            const int row_tiles = (rows + 16 * mi - 1) / (16 * mi);
+            for (int k = 0; k < K; ++k) {
+                const int32_t* e = ext + (size_t)c->slot_of[(size_t)op.child * c->Kmax + k] * nb * 2;
+                for (int rt = 0; rt < row_tiles; ++rt) {
+                    int lo = 0x7fffffff, hi = -1;
+                    for (int b = rt * mi; b < rt * mi + mi && b < nb; ++b) { lo = std::min(lo, e[2 * b]); hi = std::max(hi, e[2 * b + 1]); }
+                    int nkt = n_k;
+                    if (hi >= lo) nkt = std::min(hi, c->M) / kBK - lo / kBK + 1; else nkt = 1;
+                    work += (nkt + overhead) * mi * n_col_tiles;
+                }
             }
+            tiles += (double)row_tiles * K * n_col_tiles;
         }
-        const double tiles = (double)row_tiles * K * n_col_tiles;
-        const double avg_tile = work / ((double)row_tiles * K);
         const double rounds = std::ceil(tiles / slots);
-        const double cost = std::max(work * n_col_tiles / slots, rounds * avg_tile) * eff[mi];
+        const double cost = std::max(work / slots, rounds * (work / tiles)) * eff[mi];
         if (cost < best_cost * (1.0 - 1e-9)) { best_cost = cost; best = mi; }
     }
     return best;
 }
 
+// Host side of a call's launches for K categories and a chunk `cols` columns wide: the tile height of every K2 group (from
+// the previous call's extents when there are any), the per-op row-tile counts, the planner's descriptors.  sync: upload now
+// (before a graph capture); otherwise on `s`, and only what changed since the last call.
+int prepare_descriptors(cafe_ctx* c, DescSet& ds, int K, int64_t cols, const std::vector<int32_t>* prev_ext, bool sync, hipStream_t s, bool* plan_needed) {
+    const size_t n_ops = c->h_gemm_ops.size();
+    if (!ds.d_gemm_ops) {
+        HIP_TRY(c, hipMalloc(&ds.d_gemm_ops, sizeof(GemmOp) * n_ops));
+        HIP_TRY(c, hipMalloc(&ds.d_plan_desc, sizeof(PlanLaunch) * std::max(1, c->n_gemm_groups)));
+        HIP_TRY(c, hipMalloc(&ds.d_plan, sizeof(int2) * std::max<size_t>(1, c->plan_entries)));
+    }
+    ds.group_mi.assign(c->n_gemm_groups, 0);
+    ds.group_blocks.assign(c->n_gemm_groups, 0);
+    ds.group_rounds.assign(c->n_gemm_groups, 0);
+    ds.group_plan_off.assign(c->n_gemm_groups, 0);
+    std::vector<GemmOp> ops = c->h_gemm_ops;
+    std::vector<PlanLaunch> plans(c->n_gemm_groups);
+    const int slots = 2 * c->n_cu / 8 * 8;
+    size_t used = 0;
+    int gi = 0;
+    for (const Group& g : c->groups) {
+        if (g.type != 1) continue;
+        int mi = c->force_mi;                               // 0: picked per launch
+        if (!mi && prev_ext) mi = pick_tile_height(c, prev_ext->data(), g, K, cols);
+        if (!mi) {                                          // no extents (yet): whole rounds x height
+            int64_t tiles_by_mi[10] = {0};
+            for (int h = 4; h <= 9; ++h)
+                for (int oi : g.ops) {
+                    const Op& op = c->ops[oi];
+                    const int64_t gc = c->subtree_dedup ? c->pat_cols[op.child] : cols;
+                    tiles_by_mi[h] += (int64_t)(((op.to_root ? c->R : c->M) + 16 * h - 1) / (16 * h)) * (gc / kBN) * K;
+                }
+            mi = prune_gemm_pick_mi(tiles_by_mi, slots);
+        }
+        int64_t tiles0 = 0;
+        for (int oi : g.ops) {
+            const Op& op = c->ops[oi];
+            GemmOp& d = ops[op.desc];
+            d.n_row_tiles = (d.rows + 16 * mi - 1) / (16 * mi);
+            const int64_t gc = c->subtree_dedup ? c->pat_cols[op.child] : cols;
+            tiles0 += prune_gemm_tiles_xcd0(K, (int)(gc / kBN), d.n_row_tiles);
+        }
+        const int blocks = prune_gemm_blocks(tiles0, c->n_cu), nlb = blocks / 8;
+        const int rounds = (int)((tiles0 + nlb - 1) / nlb) + kPlanSlack;
+        const size_t need = (size_t)8 * nlb * rounds;
+        if (used + need > c->plan_entries) { set_err(c, "internal: tile lists do not fit (%zu + %zu > %zu)", used, need, c->plan_entries); return CAFE_ERR_STATE; }
+        PlanLaunch& L = plans[gi];
+        L = PlanLaunch{};
+        L.aext = c->kpool.ext; L.ext_blocks = c->kpool.ext_blocks;
+        L.ops = ds.d_gemm_ops + g.first_desc; L.n_ops = (int)g.ops.size();
+        L.uniform_ld = c->subtree_dedup || c->grouped ? 0 : (int32_t)cols;
+        L.mi = mi; L.n_categories = K; L.k_valid = c->M + 1;
+        L.blocks_per_xcd = nlb; L.rounds = rounds; L.fixed = c->plan_fixed; L.bias = c->plan_bias;
+        L.plan = ds.d_plan + used;
+        ds.group_mi[gi] = mi; ds.group_blocks[gi] = blocks; ds.group_rounds[gi] = rounds; ds.group_plan_off[gi] = used;
+        used += need;
+        ++gi;
+    }
+    const bool ops_same = ds.gemm_ops_sent.size() == n_ops && std::memcmp(ds.gemm_ops_sent.data(), ops.data(), sizeof(GemmOp) * n_ops) == 0;
+    const bool plans_same = ds.plan_desc_sent.size() == plans.size() &&
+                            (plans.empty() || std::memcmp(ds.plan_desc_sent.data(), plans.data(), sizeof(PlanLaunch) * plans.size()) == 0);
+    if (!ops_same) {
+        if (sync) {
+            HIP_TRY(c, hipMemcpy(ds.d_gemm_ops, ops.data(), sizeof(GemmOp) * n_ops, hipMemcpyHostToDevice));
+        } else {
+            std::memcpy(c->h_gemm_stage, ops.data(), sizeof(GemmOp) * n_ops);       // (the previous upload from here was waited for: ev_upload)
+            HIP_TRY(c, hipMemcpyAsync(ds.d_gemm_ops, c->h_gemm_stage, sizeof(GemmOp) * n_ops, hipMemcpyHostToDevice, s));
+        }
+        ds.gemm_ops_sent = ops;
+    }
+    if (!plans_same && !plans.empty()) {
+        if (sync) {
+            HIP_TRY(c, hipMemcpy(ds.d_plan_desc, plans.data(), sizeof(PlanLaunch) * plans.size(), hipMemcpyHostToDevice));
+        } else {
+            std::memcpy(c->h_plan_desc, plans.data(), sizeof(PlanLaunch) * plans.size());
+            HIP_TRY(c, hipMemcpyAsync(ds.d_plan_desc, c->h_plan_desc, sizeof(PlanLaunch) * plans.size(), hipMemcpyHostToDevice, s));
+        }
+        ds.plan_desc_sent = plans;
+    }
+    // with extents the lists follow this call's matrices: planned every call; without, only when something they depend on changed
+    const bool static_ok = ds.plan_static_valid && ds.plan_static_K == K && ds.plan_static_cols == cols && ops_same && plans_same;
+    *plan_needed = c->kpool.ext != nullptr || !static_ok;
+    ds.plan_static_valid = true; ds.plan_static_K = K; ds.plan_static_cols = cols;
+    return CAFE_OK;
+}
+
 // The device work of one call, enqueued on `s` (or recorded into a graph being captured on `s`): parameter upload,
 // K1, the schedule (K2 / K3 launches), K4, the final sum into d_out.  Everything that changes between calls of the
 // same shape travels through the parameter block; kernel arguments depend only on (reduction, K, error model).
-int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, double* d_out, hipStream_t s, bool events, bool capturing) {
+int record_call(cafe_ctx* c, DescSet& ds, int K, bool gamma, bool rootmax, bool use_err, double* d_out, hipStream_t s, bool events, bool capturing) {
     c->stats.gemm_flops = c->stats.gemm_bytes = c->stats.gemm_flops_per_family = c->stats.gemm_flops_dense = 0;
     c->stats.gemm_launches = 0;
+    c->desc_last = &ds;
+    // ---- host: tile heights and descriptors (the previous call's extents are in h_ext: that call was waited for)
+    const bool have_ext = c->h_ext && c->h_ext_valid && c->h_ext_K == K;       // the previous call's extents (same shape)
+    std::vector<int32_t> prev_ext;
+    if (have_ext) prev_ext.assign(c->h_ext, c->h_ext + (size_t)2 * c->n_kslots_last * c->kpool.ext_blocks);
+    bool plan_needed = true;
+    const int64_t cols0 = std::min<int64_t>(c->chunk_cols, c->Fp);
+    if (!capturing) {                        // (a capture's descriptors were prepared and uploaded before it began)
+        const int rc = prepare_descriptors(c, ds, K, cols0, have_ext ? &prev_ext : nullptr, false, s, &plan_needed);
+        if (rc != CAFE_OK) return rc;
+    }
+    if (c->panels_dirty) {                   // the last call returned NaN: no stale NaN may meet a zero of a padded K step
+        HIP_TRY(c, hipMemsetAsync(c->d_panels, 0, (size_t)c->stats.panel_bytes, s));
+        c->panels_dirty = false;
+    }
     HIP_TRY(c, hipMemcpyAsync(c->d_params, c->h_stage, c->params_bytes, hipMemcpyHostToDevice, s));
     if (events) HIP_TRY(c, hipEventRecord(c->ev[0], s));
     HIP_TRY(c, launch_bd_matrix_build_both(c->pool, c->kpool, c->d_slots, c->d_slots + c->max_slots, c->n_slots_last, c->n_kslots_last, s));
@@ -877,9 +1146,6 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
         set_err(c, "injected failure (cafe_debug_fail_next)");
         return CAFE_ERR_DEVICE;
     }
-    const bool have_ext = c->h_ext && c->h_ext_valid && c->h_ext_K == K;       // the previous call's extents (same shape)
-    std::vector<int32_t> prev_ext;
-    if (have_ext) prev_ext.assign(c->h_ext, c->h_ext + (size_t)2 * c->n_kslots_last * c->kpool.ext_blocks);
     if (c->h_ext) {                          // this call's extents for the next one; lands while the K2 launches run
         HIP_TRY(c, hipMemcpyAsync(c->h_ext, c->kpool.ext, sizeof(int32_t) * 2 * (size_t)c->n_kslots_last * c->kpool.ext_blocks, hipMemcpyDeviceToHost, s));
         c->h_ext_valid = true;
@@ -898,189 +1164,80 @@ int record_call(cafe_ctx* c, int K, bool gamma, bool rootmax, bool use_err, doub
         }
     }
 
-    // ---- tile heights of the K2 launches, and (one column chunk, extents on) their tile lists
-    std::vector<int> op_mi(c->ops.size(), 0);
-    std::vector<const int2*> op_plan(c->ops.size(), nullptr);
-    std::vector<int> op_rounds(c->ops.size(), 0);
-    {
-        size_t used = 0;
-        int n_desc = 0;
-        for (size_t i = 0; i < c->ops.size(); ++i) {
-            const Op& op = c->ops[i];
-            if (op.type != 1) continue;
-            const int64_t gc = c->subtree_dedup ? c->pat_cols[op.child] : std::min<int64_t>(c->chunk_cols, c->Fp);
-            const int rows = op.to_root ? c->R : c->M;
-            const int nct = (int)(gc / kBN);
-            int mi = c->force_mi;                           // 0: picked per launch
-            if (!mi && have_ext) mi = pick_tile_height(c, prev_ext.data(), op.child, rows, nct, K);
-            if (!mi) mi = prune_gemm_pick_mi(rows, nct, K, 2 * c->n_cu / 8 * 8);   // no extents yet: whole rounds x height
-            op_mi[i] = mi;
-            if (!c->use_plan || capturing) continue;      // (a captured graph would replay one shared descriptor block)
-            const int nrt = (rows + 16 * mi - 1) / (16 * mi);
-            const int nlb = prune_gemm_blocks(K, nct, nrt, c->n_cu) / 8;
-            const int64_t tiles = (((int64_t)K * nct + 7) / 8) * nrt;
-            const int rounds = (int)((tiles + nlb - 1) / nlb) + kPlanSlack;
-            const size_t need = (size_t)8 * nlb * rounds;
-            if (used + need > c->plan_entries) continue;    // (cannot happen: the room was sized for the tallest list)
-            PlanLaunch& d = c->h_plan_desc[n_desc];
-            d = PlanLaunch{};
-            d.aext = c->kpool.ext; d.ext_blocks = c->kpool.ext_blocks;
-            for (int k = 0; k < K; ++k) d.slot[k] = c->slot_of[(size_t)op.child * c->Kmax + k];
-            d.bext = c->panel_extents ? c->d_tileext[op.child] : nullptr;
-            d.mi = mi; d.n_row_tiles = nrt; d.n_col_tiles = nct; d.n_categories = K; d.k_valid = c->M + 1;
-            d.blocks_per_xcd = nlb; d.rounds = rounds; d.plan = c->d_plan + used;
-            d.fixed = c->plan_fixed; d.bias = c->plan_bias;
-            op_plan[i] = d.plan; op_rounds[i] = rounds;
-            used += need;
-            ++n_desc;
-        }
-        if (n_desc > 0) {
-            const bool same = c->plan_desc_sent.size() == (size_t)n_desc &&
-                              std::memcmp(c->plan_desc_sent.data(), c->h_plan_desc, sizeof(PlanLaunch) * n_desc) == 0;
-            if (!same) {
-                HIP_TRY(c, hipMemcpyAsync(c->d_plan_desc, c->h_plan_desc, sizeof(PlanLaunch) * n_desc, hipMemcpyHostToDevice, s));
-                c->plan_desc_sent.assign(c->h_plan_desc, c->h_plan_desc + n_desc);
-            }
-            HIP_TRY(c, launch_tile_plan(c->d_plan_desc, n_desc, s));
-        }
-        c->plan_launches_last = n_desc;
-    }
-
-    // ---- launch order.  Two streams (experimental): the side subtree's launches are enqueued alternately with the main one's
-    // so that both streams have work from the start; the root's launches come last, behind the join.
-    const bool two_streams = c->n_streams == 2 && !capturing && c->stream2;
-    std::vector<size_t> launch_order;
-    {
-        std::vector<size_t> q[2], tail;
-        for (size_t i = 0; i < c->ops.size(); ++i) {
-            const Op& op = c->ops[i];
-            if (two_streams && op.parent == c->root) tail.push_back(i);
-            else q[two_streams ? op.stream : 0].push_back(i);
-        }
-        size_t a = 0, b = 0;
-        while (a < q[0].size() || b < q[1].size()) {      // proportional merge
-            if (b >= q[1].size() || (a < q[0].size() && a * q[1].size() <= b * q[0].size())) launch_order.push_back(q[0][a++]);
-            else launch_order.push_back(q[1][b++]);
-        }
-        launch_order.insert(launch_order.end(), tail.begin(), tail.end());
-    }
-    bool forked = false;
-    if (two_streams) {
-        bool any_side = false;
-        for (const Op& op : c->ops) any_side = any_side || op.stream == 1;
-        if (any_side) {
-            HIP_TRY(c, hipEventRecord(c->ev_fork, s));      // behind K1, the extent kernels and the planner
-            HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-            forked = true;
-        }
-    }
-    bool joined = false;
-
-    // ---- prune, chunk by chunk
+    // ---- prune, chunk by chunk (one chunk unless the workspace is limited)
     c->gemm_ev_used = 0;
     c->gemm_launches_info.clear();
+    int64_t planned_cols = cols0;
     for (int64_t f0 = 0; f0 < c->Fp; f0 += c->chunk_cols) {
         const int64_t cols = std::min<int64_t>(c->chunk_cols, c->Fp - f0);
-        // columns (and leading dimension) of a node's panel: one per distinct leaf-count pattern under it, or the chunk
-        auto cols_of = [&](int v) -> int64_t { return c->subtree_dedup ? c->pat_cols[v] : cols; };
-        for (const size_t op_index : launch_order) {
-            const Op& op = c->ops[op_index];
-            hipStream_t ls = (forked && op.stream == 1 && op.parent != c->root) ? c->stream2 : s;      // this op's stream
-            if (forked && !joined && op.parent == c->root) {
-                HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
-                HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
-                joined = true;
+        const int uniform_ld = (c->subtree_dedup || c->grouped) ? 0 : (int)cols;
+        if (cols != planned_cols) {          // the last chunk is narrower: its own descriptors and lists (same stream: in order)
+            if (capturing) { set_err(c, "internal: a captured call cannot re-plan for a narrower last chunk"); return CAFE_ERR_STATE; }
+            HIP_TRY(c, hipStreamSynchronize(s));             // the descriptors (and their pinned stage) are still in use by the chunks before
+            const int rc = prepare_descriptors(c, ds, K, cols, have_ext ? &prev_ext : nullptr, false, s, &plan_needed);
+            if (rc != CAFE_OK) return rc;
+            plan_needed = true;
+            planned_cols = cols;
+            ds.plan_static_valid = false;
+        }
+        if (plan_needed && c->n_gemm_groups > 0) HIP_TRY(c, launch_tile_plan(ds.d_plan_desc, c->n_gemm_groups, s));
+        plan_needed = false;
+        int gi = 0;
+        for (size_t g_index = 0; g_index < c->groups.size(); ++g_index) {
+            const Group& g = c->groups[g_index];
+            if (g.type == 0) {
+                GatherGroup gg{};
+                gg.pool = c->pool;
+                gg.ops = c->d_gather_ops + g.first_desc; gg.n_ops = (int)g.ops.size(); gg.n_categories = K;
+                gg.max_family_size = c->M;
+                gg.err = use_err ? c->d_err : nullptr; gg.n_dev = use_err ? c->n_dev : 0;
+                gg.uniform_ld = uniform_ld;
+                gg.f0 = c->subtree_dedup ? 0 : f0;
+                HIP_TRY(c, launch_leaf_gather_group(gg, c->h_gather_ops.data() + g.first_desc, s));
+                continue;
             }
-            const int rows = op.to_root ? c->R : c->M + 1;
-            const int rows_store = op.to_root ? c->R : c->kc;
-            double* dst = c->d_panels + (int64_t)op.dst_panel * c->panel_stride;
-            // the leaf children's observed counts per column of the parent's panel
-            const int32_t* cnt_base = c->subtree_dedup ? c->d_leaf_cnt[op.parent] : c->d_counts;
-            const int64_t cnt_ld = c->subtree_dedup ? c->pat_cols[op.parent] : c->Fp;
-            const int64_t cnt_f0 = c->subtree_dedup ? 0 : f0;
-            auto cnt_row = [&](int leaf) { return c->subtree_dedup ? c->leaf_rank[leaf] : c->leaf_taxon[leaf]; };
-            if (op.type == 0) {
-                GatherArgs g{};
-                g.pool = c->pool;
-                g.n_leaf = op.n_leaf;
-                for (int l = 0; l < op.n_leaf; ++l) {
-                    g.taxon[l] = cnt_row(op.leaf_node[l]);
-                    for (int k = 0; k < K; ++k) g.slot[l][k] = c->slot_of[(size_t)op.leaf_node[l] * c->Kmax + k];
-                }
-                g.counts = cnt_base; g.counts_ld = cnt_ld; g.f0 = cnt_f0;
-                g.dst = dst; g.panel_kstride = c->panel_kstride; g.ld = (int)cols_of(op.parent);
-                g.row_off = op.to_root ? 1 : 0; g.rows = rows; g.rows_store = rows_store; g.mode = op.mode;
-                g.err = use_err ? c->d_err : nullptr; g.n_dev = use_err ? c->n_dev : 0; g.max_family_size = c->M;
-                g.n_src = op.n_src;
-                for (int j = 0; j < op.n_src; ++j) {
-                    g.src[j] = c->d_panels + (int64_t)op.src_panels[j] * c->panel_stride;
-                    g.ld_src[j] = c->factor_ld;
-                    g.map[j] = c->d_edge_map[op.src_child[j]];
-                }
-                // (the root's vector is read whole by the reduction and has no extent record)
-                g.tileext = c->panel_extents && !op.to_root && !c->no_asm_skip ? c->d_tileext[op.parent] : nullptr;
-                HIP_TRY(c, launch_leaf_gather(g, K, ls));
+            GemmArgs a{};
+            a.pool = c->kpool; a.lpool = c->pool;
+            a.ops = ds.d_gemm_ops + g.first_desc; a.n_ops = (int)g.ops.size();
+            a.k_valid = c->M + 1; a.mi = ds.group_mi[gi]; a.n_categories = K;
+            a.uniform_ld = uniform_ld;
+            a.f0 = c->subtree_dedup ? 0 : f0;
+            a.err = use_err ? c->d_err : nullptr; a.max_family_size = c->M;
+            a.stamps = (c->stamps_launch < 0 || c->stamps_launch == (long)c->stats.gemm_launches) ? c->d_stamps : nullptr;
+            a.plan = ds.d_plan + ds.group_plan_off[gi]; a.plan_rounds = ds.group_rounds[gi];
+            if (events && c->gemm_ev_used + 2 <= c->gemm_ev.size()) {       // start / stop events ride on the dispatch itself
+                HIP_TRY(c, launch_prune_gemm(a, g.variant, ds.group_blocks[gi], s, c->gemm_ev[c->gemm_ev_used], c->gemm_ev[c->gemm_ev_used + 1]));
+                c->gemm_ev_used += 2;
             } else {
-                GemmArgs g{};
-                g.pool = c->kpool;
-                for (int k = 0; k < K; ++k) g.slot[k] = c->slot_of[(size_t)op.child * c->Kmax + k];
-                g.src = c->d_panels + (int64_t)op.src_panel * c->panel_stride;
-                const int64_t gc = cols_of(op.child);       // the GEMM runs over the child's columns (= the parent's when direct)
-                g.dst = dst; g.panel_kstride = c->panel_kstride; g.ld = (int)gc; g.k_valid = c->M + 1;
-                g.rows = op.to_root ? c->R : c->M;           // parent sizes 1..rows
-                g.out_off = op.to_root ? 0 : 1;
-                g.mode = op.mode;
-                g.dst_ldt = op.to_factor ? c->factor_ld : 0;
-                g.mi = op_mi[&op - c->ops.data()];
-                g.plan = op_plan[&op - c->ops.data()];
-                g.plan_rounds = op_rounds[&op - c->ops.data()];
-                g.n_row_tiles = (g.rows + 16 * g.mi - 1) / (16 * g.mi);
-                g.n_col_tiles = (int)(gc / kBN);
-                g.stamps = (c->stamps_launch < 0 || c->stamps_launch == (long)c->stats.gemm_launches) ? c->d_stamps : nullptr;
-                g.lpool = c->pool;
-                g.n_leaf = op.n_leaf;
-                for (int l = 0; l < op.n_leaf; ++l) {
-                    g.taxon[l] = cnt_row(op.leaf_node[l]);
-                    for (int k = 0; k < K; ++k) g.leaf_slot[l][k] = c->slot_of[(size_t)op.leaf_node[l] * c->Kmax + k];
-                }
-                g.counts = cnt_base; g.counts_ld = cnt_ld; g.f0 = cnt_f0;
-                g.err = use_err ? c->d_err : nullptr; g.n_dev = use_err ? c->n_dev : 0; g.max_family_size = c->M;
-                g.bext = c->panel_extents ? c->d_tileext[op.child] : nullptr;
-                if (op.has_gath) {
-                    g.gath_src = c->d_panels + (int64_t)op.gath_panel * c->panel_stride;
-                    g.gath_ld = c->factor_ld;
-                    g.gath_map = c->d_edge_map[op.gath_child];
-                }
-                if (events && c->gemm_ev_used + 2 <= c->gemm_ev.size()) {       // start / stop events ride on the dispatch itself
-                    HIP_TRY(c, launch_prune_gemm(g, K, c->n_cu, ls, c->gemm_ev[c->gemm_ev_used], c->gemm_ev[c->gemm_ev_used + 1]));
-                    c->gemm_ev_used += 2;
-                } else {
-                    HIP_TRY(c, launch_prune_gemm(g, K, c->n_cu, ls));
-                }
-                c->stats.gemm_launches += 1;
-                c->gemm_launches_info.push_back({op.child, g.rows, gc, K, g.mi});
-                c->stats.gemm_flops_dense += 2.0 * rows * (c->M + 1) * (double)gc * K;
-                c->stats.gemm_flops += 2.0 * rows * (c->M + 1) * (double)gc * K;      // (cafe_executed_flops counts what the tiles really ran)
+                HIP_TRY(c, launch_prune_gemm(a, g.variant, ds.group_blocks[gi], s));
+            }
+            c->stats.gemm_launches += 1;
+            c->gemm_launches_info.push_back({(int)g_index, K, a.mi, cols});
+            for (int oi : g.ops) {
+                const Op& op = c->ops[oi];
+                const double gc = (double)(c->subtree_dedup ? c->pat_cols[op.child] : cols);
+                const int rows = op.to_root ? c->R : c->M;
+                c->stats.gemm_flops_dense += 2.0 * rows * (c->M + 1) * gc * K;
+                c->stats.gemm_flops += 2.0 * rows * (c->M + 1) * gc * K;      // (cafe_executed_flops counts what the tiles really ran)
                 c->stats.gemm_flops_per_family += 2.0 * rows * (c->M + 1) * (double)cols * K;
                 c->stats.gemm_bytes += 8.0 * K * ((double)rows * (c->M + 1) + (double)(c->M + 1) * gc + (double)rows * gc);
             }
-        }
-        if (forked && !joined) {                           // (no launch of the root's came by: cannot happen, the root has ops)
-            HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
-            HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
-            joined = true;
+            ++gi;
         }
         if (events && f0 + c->chunk_cols >= c->Fp) HIP_TRY(c, hipEventRecord(c->ev[2], s));
         ReduceArgs r{};
-        r.root = c->d_panels + (int64_t)c->root_panel * c->panel_stride;
-        r.panel_kstride = c->panel_kstride; r.ld = (int)cols; r.R = c->R; r.K = K; r.model = rootmax ? 2 : (gamma ? 1 : 0);
+        r.root = c->d_panels + c->panels[c->root_panel].offset;
+        r.panel_kstride = c->panels[c->root_panel].kstride; r.ld = (int)cols; r.R = c->R; r.K = K; r.model = rootmax ? 2 : (gamma ? 1 : 0);
         r.prior = c->d_prior; r.log_prior = c->d_logprior; r.cat_probs = c->d_catprobs;
         r.f0 = f0; r.nf = std::max<int64_t>(0, std::min<int64_t>(cols, c->F_uniq - f0));
         r.fam_out = c->d_fam_out; r.fam_lik = c->d_fam_lik; r.cat_out = c->d_cat_out; r.failed = c->d_failed;
         HIP_TRY(c, launch_root_reduce(r, s));
         c->last_chunk_f0 = f0;
         c->last_chunk_nf = r.nf;
+        // (several chunks with extents: the lists depend on this chunk's panel extents -- none: extents need one chunk -- and
+        // on the matrices, the same for every chunk: no re-plan)
     }
+    c->plan_launches_last = c->n_gemm_groups;
     // (the pair also goes straight into pinned host memory: cafe_score without a communicator reads it there after the
     // stream has drained, no device-to-host copy)
     HIP_TRY(c, launch_final_sum(c->d_fam_out, c->d_weights, c->d_failed, c->F_uniq, c->d_scratch, c->n_scratch, d_out, c->h_result, s));
@@ -1142,22 +1299,33 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bo
 
     const bool graph_ok = c->use_graph && !c->profile && !c->d_stamps && c->force_mi == 0;
     if (!graph_ok) {
-        const int rc = record_call(c, K, gamma, rootmax, use_err, d_out, s, c->profile != 0, false);
+        const int rc = record_call(c, c->desc, K, gamma, rootmax, use_err, d_out, s, c->profile != 0, false);
         if (rc != CAFE_OK) return rc;
     } else {
         const int key = (rootmax ? 2 : (gamma ? 1 : 0)) + 4 * K;
         cafe_ctx::CallGraph& cg = c->graphs[key];
+        auto drop = [&]() { hipFree(cg.desc.d_gemm_ops); hipFree(cg.desc.d_plan_desc); hipFree(cg.desc.d_plan); c->graphs.erase(key); };
         if (!cg.exec) {
-            // capture on the context's own stream (idle: calls are sequential), replay on the caller's
+            // capture on the context's own stream (idle: calls are sequential), replay on the caller's.  The graph gets
+            // descriptors and tile lists of its own, uploaded before the capture begins; its tile heights are frozen.
+            if (c->stats.n_chunks > 1) { drop(); set_err(c, "cafe_set_graphs: a call in several column chunks cannot be captured"); return CAFE_ERR_STATE; }
+            {
+                const bool have_ext = c->h_ext && c->h_ext_valid && c->h_ext_K == K;
+                std::vector<int32_t> prev_ext;
+                if (have_ext) prev_ext.assign(c->h_ext, c->h_ext + (size_t)2 * c->n_kslots_last * c->kpool.ext_blocks);
+                bool plan_needed = true;
+                const int rp = prepare_descriptors(c, cg.desc, K, std::min<int64_t>(c->chunk_cols, c->Fp), have_ext ? &prev_ext : nullptr, true, c->stream, &plan_needed);
+                if (rp != CAFE_OK) { drop(); return rp; }
+            }
             hipGraph_t graph = nullptr;
             HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-            const int rc = record_call(c, K, gamma, rootmax, use_err, c->d_result, c->stream, false, true);
+            const int rc = record_call(c, cg.desc, K, gamma, rootmax, use_err, c->d_result, c->stream, false, true);
             const hipError_t ee = hipStreamEndCapture(c->stream, &graph);
-            if (rc != CAFE_OK) { if (graph) (void)hipGraphDestroy(graph); c->graphs.erase(key); return rc; }
-            if (ee != hipSuccess || !graph) { c->graphs.erase(key); set_err(c, "hipStreamEndCapture failed: %s", hipGetErrorString(ee)); return CAFE_ERR_DEVICE; }
+            if (rc != CAFE_OK) { if (graph) (void)hipGraphDestroy(graph); drop(); return rc; }
+            if (ee != hipSuccess || !graph) { drop(); set_err(c, "hipStreamEndCapture failed: %s", hipGetErrorString(ee)); return CAFE_ERR_DEVICE; }
             const hipError_t ei = hipGraphInstantiate(&cg.exec, graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
-            if (ei != hipSuccess) { c->graphs.erase(key); set_err(c, "hipGraphInstantiate failed: %s", hipGetErrorString(ei)); return CAFE_ERR_DEVICE; }
+            if (ei != hipSuccess) { drop(); set_err(c, "hipGraphInstantiate failed: %s", hipGetErrorString(ei)); return CAFE_ERR_DEVICE; }
             cg.stats = c->stats;
         }
         const int64_t n_mat = c->stats.n_matrices;
@@ -1181,32 +1349,36 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bo
 // matrix extent x panel extent, so read the extents this call published and count, per launch, what its tiles ran.  Reads
 // the extents back (a few synchronous copies, milliseconds of host work): for measurement, once, not per call.
 double count_executed_flops(cafe_ctx* c, std::vector<double>* per_launch = nullptr) {
-    if (!c->kpool.ext || c->gemm_launches_info.empty()) return c->stats.gemm_flops;
-    // flops the K2 launches EXECUTED: K tiles outside a row tile's non-zero extent are skipped, so read the extents K1
-    // published for this call and count, per launch, what its row tiles ran (same tile height as the launcher picks)
-    {
-        const int nb = c->kpool.ext_blocks;
-        std::vector<int32_t> ext((size_t)2 * c->max_kslots * nb);
+    if (c->gemm_launches_info.empty()) return c->stats.gemm_flops;
+    const int nb = c->kpool.ext_blocks;
+    std::vector<int32_t> ext;
+    if (c->kpool.ext) {
+        ext.resize((size_t)2 * c->max_kslots * nb);
         if (hipMemcpy(ext.data(), c->kpool.ext, ext.size() * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
-        const int n_k = (c->M + 1 + kBK - 1) / kBK;
-        double executed = 0;
-        std::vector<int32_t> bext;
-        for (const auto& L : c->gemm_launches_info) {
-            const double before = executed;
-            if (per_launch) per_launch->push_back(0.0);
-            const int mi = L.mi;
-            const int bm = 16 * mi;
-            const int n_ct = (int)(L.cols / kBN);
-            const bool have_b = c->panel_extents && c->d_tileext[L.child];
+    }
+    double executed = 0;
+    std::vector<int32_t> bext;
+    for (const auto& L : c->gemm_launches_info) {
+        const double before = executed;
+        const int mi = L.mi, bm = 16 * mi;
+        for (int oi : c->groups[L.group].ops) {
+            const Op& op = c->ops[oi];
+            const int rows = op.to_root ? c->R : c->M;
+            const int64_t cols = c->subtree_dedup ? c->pat_cols[op.child] : L.cols;
+            const int n_ct = (int)(cols / kBN);
+            const bool have_b = c->kpool.ext && c->panel_extents && c->d_tileext[op.child];
             if (have_b) {
                 bext.resize((size_t)2 * L.K * n_ct);
-                if (hipMemcpy(bext.data(), c->d_tileext[L.child], bext.size() * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
+                if (hipMemcpy(bext.data(), c->d_tileext[op.child], bext.size() * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
             }
             for (int k = 0; k < L.K; ++k) {
-                const int32_t* e = ext.data() + (size_t)c->slot_of[(size_t)L.child * c->Kmax + k] * nb * 2;
-                for (int row0 = 0; row0 < L.rows; row0 += bm) {
-                    int alo = 0x7fffffff, ahi = -1;
-                    for (int b = row0 / 16; b < row0 / 16 + mi && b < nb; ++b) { alo = std::min(alo, e[2 * b]); ahi = std::max(ahi, e[2 * b + 1]); }
+                const int32_t* e = c->kpool.ext ? ext.data() + (size_t)c->slot_of[(size_t)op.child * c->Kmax + k] * nb * 2 : nullptr;
+                for (int row0 = 0; row0 < rows; row0 += bm) {
+                    int alo = 0, ahi = c->M;
+                    if (e) {
+                        alo = 0x7fffffff; ahi = -1;
+                        for (int b = row0 / 16; b < row0 / 16 + mi && b < nb; ++b) { alo = std::min(alo, e[2 * b]); ahi = std::max(ahi, e[2 * b + 1]); }
+                    }
                     for (int ct = 0; ct < (have_b ? n_ct : 1); ++ct) {
                         int lo = alo, hi = ahi;
                         if (have_b) { lo = std::max(lo, bext[((size_t)k * n_ct + ct) * 2]); hi = std::min(hi, bext[((size_t)k * n_ct + ct) * 2 + 1]); }
@@ -1214,15 +1386,14 @@ double count_executed_flops(cafe_ctx* c, std::vector<double>* per_launch = nullp
                         hi = std::min(hi, c->M);
                         const int nkt = hi / kBK - lo / kBK + 1;
                         const int kk = std::min(nkt * kBK, c->M + 1 - (lo / kBK) * kBK);      // the last K tile of the matrix is ragged
-                        executed += 2.0 * std::min(bm, L.rows - row0) * (double)kk * (have_b ? (double)kBN : (double)L.cols);
+                        executed += 2.0 * std::min(bm, rows - row0) * (double)kk * (have_b ? (double)kBN : (double)cols);
                     }
-                    (void)n_k;
                 }
             }
-            if (per_launch) per_launch->back() = executed - before;
         }
-        return executed;
+        if (per_launch) per_launch->push_back(executed - before);
     }
+    return executed;
 }
 
 void collect_stats(cafe_ctx* c) {
@@ -1380,6 +1551,7 @@ int cafe_score(cafe_ctx* ctx, const cafe_params* params, double* neg_lnl, const 
         return CAFE_ERR_DEVICE;
     }
     *neg_lnl = cafe_finish_partial(ctx->h_result);
+    if (std::isnan(ctx->h_result[0])) ctx->panels_dirty = true;        // NaNs may now sit in the panels (see record_call)
     ctx->stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     collect_stats(ctx);
     if (out) return cafe_family_results(ctx, out);
@@ -1542,32 +1714,43 @@ int cafe_executed_flops(cafe_ctx* ctx, double* flops) {
 }
 
 // diagnostic / test: read the tile lists of the last call back and check them against the extents -- every tile of every
-// planned launch exactly once, with the K range the kernel's own decode would work out, nothing behind the end of a list.
-// *n_planned: launches with a plan; *worst_load: largest planned workgroup load over the mean load of its XCD.
+// op of every launch exactly once, with the K range the extents give, nothing behind the end of a list.
+// *n_planned: K2 launches checked; *worst_load: largest planned workgroup load over the mean load of its XCD.
 int cafe_debug_plan_check(cafe_ctx* ctx, int32_t* n_planned, double* worst_load) {
     if (!ctx) return CAFE_ERR_ARGUMENT;
     if (n_planned) *n_planned = 0;
     if (worst_load) *worst_load = 1.0;
-    if (!ctx->use_plan || ctx->plan_launches_last == 0 || ctx->plan_desc_sent.empty()) return CAFE_OK;
+    const DescSet* ds = ctx->desc_last;
+    if (!ds || ctx->plan_launches_last == 0 || ds->plan_desc_sent.empty()) return CAFE_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
     const int nb = ctx->kpool.ext_blocks;
-    std::vector<int32_t> aext((size_t)2 * ctx->max_kslots * nb), bext;
-    HIP_TRY(ctx, hipMemcpy(aext.data(), ctx->kpool.ext, aext.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<int32_t> aext, bext;
+    if (ctx->kpool.ext) {
+        aext.resize((size_t)2 * ctx->max_kslots * nb);
+        HIP_TRY(ctx, hipMemcpy(aext.data(), ctx->kpool.ext, aext.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
     std::vector<int2> plan;
     double worst = 1.0;
-    for (const PlanLaunch& L : ctx->plan_desc_sent) {
+    for (const PlanLaunch& L : ds->plan_desc_sent) {
         const int nlb = L.blocks_per_xcd;
         plan.resize((size_t)8 * nlb * L.rounds);
         HIP_TRY(ctx, hipMemcpy(plan.data(), L.plan, plan.size() * sizeof(int2), hipMemcpyDeviceToHost));
-        if (L.bext) {
-            bext.resize((size_t)2 * L.n_categories * L.n_col_tiles);
-            HIP_TRY(ctx, hipMemcpy(bext.data(), L.bext, bext.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        const GemmOp* ops = ds->gemm_ops_sent.data() + (L.ops - ds->d_gemm_ops);
+        std::vector<std::vector<int32_t>> op_bext(L.n_ops);
+        for (int o = 0; o < L.n_ops; ++o) {
+            const int nct = L.uniform_ld > 0 ? L.uniform_ld / kBN : ops[o].n_col_tiles;
+            if (ops[o].bext && ctx->kpool.ext) {
+                op_bext[o].resize((size_t)2 * L.n_categories * nct);
+                HIP_TRY(ctx, hipMemcpy(op_bext[o].data(), ops[o].bext, op_bext[o].size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            }
         }
         for (int x = 0; x < 8; ++x) {
-            const int my_pairs = (L.n_categories * L.n_col_tiles - x + 7) >> 3;
-            const int n_tiles = my_pairs * L.n_row_tiles;
-            std::vector<char> seen((size_t)n_tiles, 0);
+            std::vector<std::vector<char>> seen(L.n_ops);
+            for (int o = 0; o < L.n_ops; ++o) {
+                const int nct = L.uniform_ld > 0 ? L.uniform_ld / kBN : ops[o].n_col_tiles;
+                seen[o].assign((size_t)((L.n_categories * nct - x + 7) >> 3) * ops[o].n_row_tiles, 0);
+            }
             double total = 0, top = 0;
             for (int w = 0; w < nlb; ++w) {
                 bool ended = false;
@@ -1575,27 +1758,32 @@ int cafe_debug_plan_check(cafe_ctx* ctx, int32_t* n_planned, double* worst_load)
                 for (int r = 0; r < L.rounds; ++r) {
                     const int2 e = plan[((size_t)x * nlb + w) * L.rounds + r];
                     if (e.y == 0) { ended = true; if (e.x != 0) goto bad; continue; }
-                    if (ended || e.x < 0 || e.x >= n_tiles || seen[e.x]) goto bad;
-                    seen[e.x] = 1;
-                    const int row_tile = e.x % L.n_row_tiles, pair = x + 8 * (e.x / L.n_row_tiles);
-                    const int ct = pair % L.n_col_tiles, cat = pair / L.n_col_tiles, b0 = row_tile * L.mi;
-                    const int32_t* a = aext.data() + ((size_t)L.slot[cat] * nb + b0) * 2;
-                    int lo = 0x7fffffff, hi = -1, zlo = 0;
-                    for (int b = 0; b < L.mi && b0 + b < nb; ++b) { lo = std::min(lo, a[2 * b]); hi = std::max(hi, a[2 * b + 1]); }
-                    if (L.bext) {
-                        const int32_t* be = bext.data() + ((size_t)cat * L.n_col_tiles + ct) * 2;
-                        lo = std::max(lo, be[0]); hi = std::min(hi, be[1]);
-                        if (be[1] >= be[0]) zlo = be[0];
+                    const int o = e.x >> 24, t = e.x & 0xFFFFFF;
+                    if (ended || o < 0 || o >= L.n_ops || t >= (int)seen[o].size() || seen[o][t]) goto bad;
+                    seen[o][t] = 1;
+                    const int nrt = ops[o].n_row_tiles, nct = L.uniform_ld > 0 ? L.uniform_ld / kBN : ops[o].n_col_tiles;
+                    const int row_tile = t % nrt, pair = x + 8 * (t / nrt);
+                    const int ct = pair % nct, cat = pair / nct, b0 = row_tile * L.mi;
+                    int lo = 0, hi = L.k_valid - 1, zlo = 0;
+                    if (ctx->kpool.ext) {
+                        const int32_t* a = aext.data() + ((size_t)ops[o].slot[cat] * nb + b0) * 2;
+                        lo = 0x7fffffff; hi = -1;
+                        for (int b = 0; b < L.mi && b0 + b < nb; ++b) { lo = std::min(lo, a[2 * b]); hi = std::max(hi, a[2 * b + 1]); }
+                        if (!op_bext[o].empty()) {
+                            const int32_t* be = op_bext[o].data() + ((size_t)cat * nct + ct) * 2;
+                            lo = std::max(lo, be[0]); hi = std::min(hi, be[1]);
+                            if (be[1] >= be[0]) zlo = be[0];
+                        }
+                        if (hi < lo) { lo = zlo; hi = zlo; }
+                        hi = std::min(hi, L.k_valid - 1);
                     }
-                    if (hi < lo) { lo = zlo; hi = zlo; }
-                    hi = std::min(hi, L.k_valid - 1);
                     if ((e.y >> 16) != lo / kBK || (e.y & 0xFFFF) != hi / kBK - lo / kBK + 1) goto bad;
                     load += (e.y & 0xFFFF) + L.fixed;
                 }
                 total += load;
                 top = std::max(top, load);
             }
-            for (char v : seen) if (!v) goto bad;
+            for (auto& sv : seen) for (char v : sv) if (!v) goto bad;
             if (total > 0) worst = std::max(worst, top / (total / nlb));
         }
         if (n_planned) *n_planned += 1;
@@ -1629,7 +1817,13 @@ int cafe_debug_launch_flops(cafe_ctx* ctx, double* executed, double* all_k_tiles
     for (size_t i = 0; i < n && i < v.size(); ++i) {
         const auto& L = ctx->gemm_launches_info[i];
         executed[i] = v[i];
-        if (all_k_tiles) all_k_tiles[i] = 2.0 * L.rows * (ctx->M + 1) * (double)L.cols * L.K;
+        if (all_k_tiles) {
+            all_k_tiles[i] = 0;
+            for (int oi : ctx->groups[L.group].ops) {
+                const Op& op = ctx->ops[oi];
+                all_k_tiles[i] += 2.0 * (op.to_root ? ctx->R : ctx->M) * (ctx->M + 1) * (double)(ctx->subtree_dedup ? ctx->pat_cols[op.child] : L.cols) * L.K;
+            }
+        }
         if (tile_height) tile_height[i] = L.mi;
     }
     return (int)std::min(n, v.size()) >= 0 ? CAFE_OK : CAFE_OK;
@@ -1685,7 +1879,8 @@ int cafe_get_root_likelihoods(cafe_ctx* ctx, int64_t family, int32_t category, d
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
     const int64_t cols = std::min<int64_t>(ctx->chunk_cols, ctx->Fp - ctx->last_chunk_f0);
-    const double* src = ctx->d_panels + (int64_t)ctx->root_panel * ctx->panel_stride + (int64_t)category * ctx->panel_kstride + (u - ctx->last_chunk_f0);
+    const cafe::Panel& RP = ctx->panels[ctx->root_panel];
+    const double* src = ctx->d_panels + RP.offset + (int64_t)category * RP.kstride + (u - ctx->last_chunk_f0);
     HIP_TRY(ctx, hipMemcpy2D(out, sizeof(double), src, (size_t)cols * sizeof(double), sizeof(double), (size_t)ctx->R, hipMemcpyDeviceToHost));
     return CAFE_OK;
 }

@@ -52,60 +52,76 @@ struct MatrixPool {
 
 // Likelihood panels: [category][row][family], family fastest, so that a node's panel is the
 // GEMM's B operand with the family axis as its N dimension.
-struct GemmArgs {
-    MatrixPool pool;                // k-major pool
-    int32_t slot[kMaxCategories];   // matrix of the child's branch per category
-    const double* src;              // child panel  (chunk-relative base), rows = child sizes 0..M
-    double* dst;                    // parent panel (chunk-relative base)
-    int64_t panel_kstride;          // doubles between categories of a panel
-    int32_t ld;                     // panel leading dimension = chunk columns (multiple of kBN)
-    int32_t k_valid;                // contraction extent M+1
+//
+// One K2 LAUNCH carries the GEMMs of a GROUP of mutually independent branches (the ready nodes of a tree level that share
+// an epilogue variant): per branch one GemmOp in a device array, per launch one GemmArgs by value.  A workgroup's tile list
+// (tile_plan_kernel) names, per tile, the op it belongs to; the kernel fetches that op's descriptor with scalar loads while
+// the previous tile computes.  Small nodes fill the persistent grid together and a launch's tail overlaps the next node's
+// head ("one launch (or one persistent-kernel phase) per height"; reference loop src/core.cpp:133-144).
+struct GemmOp {
+    int32_t slot[kMaxCategories];   // matrix of the child's branch per category (k-major pool)
+    const double* src;              // child panel, rows = child sizes 0..M
+    double* dst;                    // parent panel, or (dst_ldt > 0) the child's transposed factor panel
+    int64_t src_kstride;            // doubles between the categories of src / dst / gath_src
+    int64_t dst_kstride;
+    int64_t gath_kstride;
+    int32_t ld;                     // leading dimension of src and of a row-major dst = GEMM columns (multiple of kBN)
     int32_t rows;                   // GEMM rows = parent sizes 1..rows: M, or R when the parent is the root
     int32_t out_off;                // panel row of parent size 1: 1 (interior parent; row 0 is copied), 0 (root)
-    int32_t mode;                   // 0: dst = v, 1: dst *= v
-    int32_t mi;                     // row tile = 16*mi
-    int32_t n_row_tiles;
+    int32_t n_row_tiles;            // ceil(rows / (16 * GemmArgs::mi)): filled per call
     int32_t n_col_tiles;
-    int32_t n_categories;           // filled by launch_prune_gemm
-    unsigned long long* stamps;     // diagnostic: 6 words per workgroup (placement, epilogue ticks, tiles, lifetime), nullptr in production
-    // leaf siblings folded into the epilogue (K3's work for a parent with leaf and interior children)
-    MatrixPool lpool;               // row-major pool
+    // > 0: a factor GEMM, stored transposed: dst[column][16 - out_off + panel row], dst_ldt rows per column
+    int32_t dst_ldt;
+    // one leaf sibling folded into the epilogue (K3's work for a parent with one leaf and interior children)
     int32_t n_leaf;
-    int32_t taxon[kMaxLeafPerOp];
-    int32_t leaf_slot[kMaxLeafPerOp][kMaxCategories];
-    const int32_t* counts;          // [taxon][family] for the whole shard
+    int32_t taxon;                  // row of `counts`
+    int32_t leaf_slot[kMaxCategories];
+    const int32_t* counts;          // [row][column] observed counts
     int64_t counts_ld;
-    int64_t f0;                     // first family of the chunk
-    const double* err;              // [(M+1)][n_dev] or nullptr
-    int32_t n_dev;
-    int32_t max_family_size;
     // factor panel of an interior sibling with fewer distinct columns than the parent, folded into the epilogue:
-    // column f of the parent takes column gath_map[f] of the TRANSPOSED factor gath_src (kFactorLd rows per column)
+    // column f of the parent takes column gath_map[f] of the TRANSPOSED factor gath_src (gath_ld rows per column)
     const double* gath_src;
     int64_t gath_ld;
     const int32_t* gath_map;
     // per (category, column tile) of the CHILD panel: rows outside [bext[..][0], bext[..][1]] are exactly zero (extents.hip);
     // nullptr: unknown
     const int32_t* bext;
-    // > 0: this launch is a factor GEMM and stores transposed, dst[column][16 - out_off + panel row], dst_ldt rows per
-    // column (see prune_gemm.hip)
-    int32_t dst_ldt;
-    // Tile lists laid out by tile_plan_kernel (extents.hip) for this launch, or nullptr: workgroup `local` of XCD `xcd` runs
-    // the tiles plan[(xcd * blocks_per_xcd + local) * plan_rounds + i], i = 0, 1, ... until an entry with y == 0.
-    // x: index of the tile in the XCD's list (pair-major, row tile fastest), y: first K tile << 16 | number of K tiles.
+};
+
+struct GemmArgs {
+    MatrixPool pool;                // k-major pool
+    MatrixPool lpool;               // row-major pool (fused leaf siblings)
+    const GemmOp* ops;              // the group's descriptors (device memory)
+    int32_t n_ops;
+    int32_t k_valid;                // contraction extent M+1
+    int32_t mi;                     // row tile = 16*mi, the same for every op of the launch
+    int32_t n_categories;
+    int32_t uniform_ld;             // > 0 (several column chunks, one column per family): columns of every panel in this chunk;
+                                    // overrides GemmOp::ld / n_col_tiles
+    int64_t f0;                     // first family of the chunk (offset into `counts`)
+    const double* err;              // [(M+1)][3] error model of the fused leaf sibling, or nullptr
+    int32_t max_family_size;
+    unsigned long long* stamps;     // diagnostic: 6 words per workgroup (placement, epilogue ticks, tiles, lifetime), nullptr in production
+    // Tile lists laid out by tile_plan_kernel (extents.hip): workgroup `local` of XCD `xcd` runs the tiles
+    // plan[(xcd * blocks_per_xcd + local) * plan_rounds + i], i = 0, 1, ... until an entry with y == 0.
+    // x: op << 24 | index of the tile in the op's list for that XCD (pair-major, row tile fastest),
+    // y: first K tile << 16 | number of K tiles.
     const int2* plan;
     int32_t plan_rounds;
 };
+constexpr int kMaxGroupOps = 128;   // ops per K2 launch (7 bits of a plan entry)
 
 // One K2 launch as the tile planner sees it.  K loops of unequal length (zero extents) make a fixed deal of tiles uneven:
 // the planner deals each round of tiles (one per workgroup of the XCD, in the order the fixed deal would run them, so the
-// row tiles of a column tile still run together) longest tile to least-loaded workgroup.
+// row tiles of a column tile still run together) longest tile to least-loaded workgroup.  The XCD's list is the
+// concatenation of the lists of the launch's ops.
 struct PlanLaunch {
-    const int32_t* aext;            // k-major pool extents (MatrixPool::ext)
+    const int32_t* aext;            // k-major pool extents (MatrixPool::ext), or nullptr: every K tile
     int32_t ext_blocks;
-    int32_t slot[kMaxCategories];
-    const int32_t* bext;            // GemmArgs::bext
-    int32_t mi, n_row_tiles, n_col_tiles, n_categories, k_valid;
+    const GemmOp* ops;              // slot[], bext, n_row_tiles, n_col_tiles of every op
+    int32_t n_ops;
+    int32_t uniform_ld;             // as GemmArgs
+    int32_t mi, n_categories, k_valid;
     int32_t blocks_per_xcd;         // workgroups of the launch / 8
     int32_t rounds;                 // list length per workgroup
     int32_t fixed;                  // what an output tile costs beyond its K loop, in K tiles
@@ -114,33 +130,33 @@ struct PlanLaunch {
 };
 constexpr int kPlanSlack = 2;       // spare list entries per workgroup (the planner's last rounds are dealt as one batch)
 hipError_t launch_tile_plan(const PlanLaunch* d_launches, int n_launches, hipStream_t stream);
-// workgroups of a K2 launch (a multiple of 8): two per CU, fewer when the launch has fewer tiles
-int prune_gemm_blocks(int n_categories, int n_col_tiles, int n_row_tiles, int n_cu);
+// workgroups of a K2 launch (a multiple of 8) whose busiest XCD owns `tiles_xcd0` tiles: two per CU, fewer when there are fewer tiles
+int prune_gemm_blocks(int64_t tiles_xcd0, int n_cu);
+// tiles XCD 0 owns of an op with n_pairs = categories * column tiles
+inline int64_t prune_gemm_tiles_xcd0(int n_categories, int n_col_tiles, int n_row_tiles) {
+    return (((int64_t)n_categories * n_col_tiles + 7) / 8) * n_row_tiles;
+}
 
 struct GatherArgs {
-    MatrixPool pool;
     int32_t n_leaf;
     int32_t taxon[kMaxLeafPerOp];
     int32_t slot[kMaxLeafPerOp][kMaxCategories];
     const int32_t* counts;          // [taxon][family] for the whole shard
     int64_t counts_ld;
-    int64_t f0;                     // first family of the chunk
     double* dst;
-    int64_t panel_kstride;
+    int64_t panel_kstride;          // doubles between the categories of dst
     int32_t ld;
     int32_t row_off;
     int32_t rows;
     int32_t rows_store;
     int32_t mode;
-    const double* err;              // [(M+1)][n_dev] or nullptr
-    int32_t n_dev;
-    int32_t max_family_size;        // M
     // factor panels of interior children that have fewer distinct columns than this parent (subtree-level
     // de-duplication): column f of the parent takes column map[j][f] of factor j.  Factors are stored TRANSPOSED by
     // their GEMM (prune_gemm.hip, TRANS): src[j][category][column][15 + row_off + panel row], ld_src rows per column.
     int32_t n_src;
     const double* src[2];
     int64_t ld_src[2];
+    int64_t kstride_src[2];         // doubles between the categories of src[j]
     const int32_t* map[2];
     // [category][ld / 128][2] zero extent of each 128-column tile of dst (extents.hip), or nullptr: rows outside it (rounded
     // out to K2's 16-row K tiles) are neither read nor written by the assemble pass
@@ -197,10 +213,28 @@ struct ReduceArgs {
 hipError_t launch_bd_matrix_build(const MatrixPool& pool, const SlotParam* d_slots, int n_slots, hipStream_t stream);
 hipError_t launch_bd_matrix_build_both(const MatrixPool& pool, const MatrixPool& kpool, const SlotParam* d_slots, const SlotParam* d_kslots,
                                        int n_slots, int n_kslots, hipStream_t stream);
-hipError_t launch_prune_gemm(const GemmArgs& a, int n_categories, int n_cu, hipStream_t stream, hipEvent_t ev_start = nullptr,
-                             hipEvent_t ev_stop = nullptr);   // n_cu: compute units of the stream's device; events: attached to the dispatch
-int prune_gemm_pick_mi(int rows, int n_col_tiles, int n_categories, int slots);     // row-tile height (in 16-row blocks)
-hipError_t launch_leaf_gather(const GatherArgs& a, int n_categories, hipStream_t stream);
+// One launch for a group of ops.  variant: what the epilogue of EVERY op of the group does (the host groups by it):
+//   mode (0 store, 1 multiply), leaf (0 none, 1 one leaf sibling, 2 gathered sibling factor), trans (factor GEMM, transposed store).
+// blocks: prune_gemm_blocks of the group; events: attached to the dispatch.
+struct GemmVariant { int mode, leaf, trans; };
+hipError_t launch_prune_gemm(const GemmArgs& a, GemmVariant v, int blocks, hipStream_t stream, hipEvent_t ev_start = nullptr,
+                             hipEvent_t ev_stop = nullptr);
+int prune_gemm_pick_mi(int64_t row_tile_pairs_by_mi[10], int slots);     // row-tile height (in 16-row blocks) from the group's tile counts per height
+// what a K3 launch of a group of ops shares
+struct GatherGroup {
+    MatrixPool pool;                // row-major pool
+    const GatherArgs* ops;          // device array
+    int32_t n_ops;
+    int32_t n_categories;
+    int32_t max_family_size;        // M
+    const double* err;              // [(M+1)][n_dev] error model of the call, or nullptr
+    int32_t n_dev;
+    int32_t uniform_ld;             // > 0 (several column chunks): columns of every panel in this chunk, overrides GatherArgs::ld
+    int64_t f0;                     // first family of the chunk (offset into `counts`)
+};
+// One launch for a group of K3 ops of one variant (same n_leaf, n_src, mode; the error model is the call's): d_ops device
+// array, h_ops the same on the host (grid extents)
+hipError_t launch_leaf_gather_group(const GatherGroup& g, const GatherArgs* h_ops, hipStream_t stream);
 hipError_t launch_root_reduce(const ReduceArgs& a, hipStream_t stream);
 // sum_f w_f * fam_out[f] and the number of failed families -> out[0], out[1] (and out_host[0..1] when not null: pinned host memory)
 hipError_t launch_final_sum(const double* fam_out, const double* weights, const int32_t* failed, int64_t n,

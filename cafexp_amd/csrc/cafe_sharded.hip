@@ -111,6 +111,7 @@ int read_tree(const cafe_problem* p, TreeShape& t) {
 
 }  // namespace
 
+constexpr double kFamilyCols = 5.0;   // what a family costs beyond its columns (K4, the passes near the root), in columns: fitted at the bench shape
 // Shard plan.  prev[v][i]: for interior non-root node v, the previous position (in shard order) whose leaf counts under
 // v equal those of position i, or -1: a shard [a, b) then holds #{i in [a,b) : prev[v][i] < a} distinct columns at v.
 struct ShardModel {
@@ -120,7 +121,7 @@ struct ShardModel {
     std::vector<int> nodes;                        // interior non-root nodes
     std::vector<std::vector<int64_t>> prev;        // [nodes.size()][F]
     std::vector<std::vector<float>> weight;        // [nodes.size()][F] cost of the position's column at that node (see shard_cost)
-    std::vector<double> fam_cum;                   // [F + 1] prefix sums of the per-family term (5 columns' worth x the family's scale)
+    std::vector<double> fam_cum;                   // [F + 1] prefix sums of the per-family term (kFamilyCols columns' worth x the family's scale)
     int rows_inner = 0, rows_root = 0, categories = 1;
 };
 
@@ -173,7 +174,10 @@ int build_shard_model(const cafe_problem* p, ShardModel& m, const double* family
             for (int u : leaves) key[k++] = p->counts[m.order[i] * T + m.tree.leaf_taxon[u]];
             int32_t big = 0;                           // largest count under v: K2 skips the all-zero rows of a column tile, and
             for (int t : under) big = std::max(big, p->counts[m.order[i] * T + t]);   // columns of large families have few
-            wt[i] = 1.0f + 2.0f * (float)std::max(0, big - 100) / (float)std::max(1, p->max_family_size);
+            // (fitted at M = 720: weight 1 up to a largest count of 100 = 0.14 M, +2 per M beyond)
+            wt[i] = 1.0f;
+            if (std::max(p->max_family_size, p->max_root_family_size) + 1 >= 256)      // (the library keeps no zero extents below that order: cafe_create)
+                wt[i] += 2.0f * std::max(0.0f, (float)big - 0.14f * (float)p->max_family_size) / (float)std::max(1, p->max_family_size);
             if (family_scale) wt[i] *= (float)family_scale[m.order[i]];
             std::string ks(reinterpret_cast<const char*>(key.data()), sizeof(int32_t) * kw);
             auto it = seen.find(ks);
@@ -192,13 +196,13 @@ int build_shard_model(const cafe_problem* p, ShardModel& m, const double* family
         m.weight.push_back(std::move(wt));
     }
     m.fam_cum.assign(F + 1, 0.0);
-    for (int64_t i = 0; i < F; ++i) m.fam_cum[i + 1] = m.fam_cum[i] + 5.0 * (family_scale ? family_scale[m.order[i]] : 1.0);
+    for (int64_t i = 0; i < F; ++i) m.fam_cum[i + 1] = m.fam_cum[i] + kFamilyCols * (family_scale ? family_scale[m.order[i]] : 1.0);
     return CAFE_OK;
 }
 
 // Predicted device time of the shard [a, b), in columns: every interior branch costs one K2 launch and the memory passes
-// of the node's panel, both linear in the node's distinct columns, plus half a column tile of padding and a launch's fixed
-// cost (about 200 columns' worth at the bench shape); the two branches under the root run over one column per family, and what
+// of the node's panel, both linear in the node's distinct columns (the per-node constants -- padding, a launch's fixed cost --
+// are the same for every shard and are left out); the two branches under the root run over one column per family, and what
 // else is linear in the families (the assemble passes near the root, K4) adds 5 columns' worth per family (fitted: with 2 the
 // shard of the smallest families, 11 500 of 50 000, ran 1 ms longer than the others outside K2).  A
 // column's weight is 1 up to a largest count of 100 under the node and grows by 2 per M beyond: K2 runs only the K tiles
@@ -214,7 +218,8 @@ double shard_cost(const ShardModel& m, int64_t a, int64_t b) {
         const std::vector<float>& wt = m.weight[j];
         double cols = 0;
         for (int64_t i = a; i < b; ++i) cols += pv[i] < a ? wt[i] : 0.0f;
-        cost += cols + 64.0 + 200.0;
+        cost += cols;                                  // (+ half a column tile of padding and the op's fixed cost: the same for every
+                                                       //  shard -- every shard runs every node -- so they drop out of the comparison)
     }
     return cost + (m.fam_cum[b] - m.fam_cum[a]);
 }
@@ -225,11 +230,12 @@ int plan_shards(const ShardModel& m, int n_shards, std::vector<int64_t>& bounds)
     bounds.assign(n_shards + 1, 0);
     bounds[n_shards] = F;
     if (n_shards == 1) return CAFE_OK;
-    // start: equal cumulative cost, a family's cost being the number of nodes at which it is the first of the whole
-    // table (in shard order) to show its pattern
+    // start: equal cumulative cost, a family's cost being its own term plus the (weighted) number of nodes at which it is
+    // the first of the whole table (in shard order) to show its pattern
     std::vector<double> cum(F, 0.0);
+    for (int64_t i = 0; i < F; ++i) cum[i] = m.fam_cum[i + 1] - m.fam_cum[i];
     for (size_t j = 0; j < m.nodes.size(); ++j)
-        for (int64_t i = 0; i < F; ++i) cum[i] += m.prev[j][i] < 0;
+        for (int64_t i = 0; i < F; ++i) cum[i] += m.prev[j][i] < 0 ? m.weight[j][i] : 0.0f;
     for (int64_t i = 1; i < F; ++i) cum[i] += cum[i - 1];
     for (int r = 1; r < n_shards; ++r)
         bounds[r] = std::lower_bound(cum.begin(), cum.end(), cum[F - 1] * r / n_shards) - cum.begin();

@@ -79,27 +79,36 @@ constexpr int kPlanTail = 3;
 // a CU, and the one dispatched first (j < 32) wins the MFMA arbitration: given equal lists it ALWAYS finishes first, 8 % of
 // the launch earlier, and the CU runs one workgroup to the end (tools/gemm_timeline.py).  The planner therefore charges a
 // tile `bias` percent less to j < 32 and as much more to j >= 32, so that the favoured workgroup takes more of the work.
-// K range of tile t of XCD `xcd`'s list (the same arithmetic as the kernel's own decode, prune_gemm.hip)
-__device__ inline void plan_tile_range(const PlanLaunch& L, int xcd, int t, int& kt0, int& nkt) {
-    const int row_tile = t % L.n_row_tiles;
-    const int pair = xcd + 8 * (t / L.n_row_tiles);
-    const int ct = pair % L.n_col_tiles, cat = pair / L.n_col_tiles;
-    const int b0 = row_tile * L.mi;
-    const int32_t* e = L.aext + ((int64_t)L.slot[cat] * L.ext_blocks + b0) * 2;
-    int lo = 0x7fffffff, hi = -1;
-    for (int b = 0; b < L.mi; ++b)
-        if (b0 + b < L.ext_blocks) { lo = min(lo, e[2 * b]); hi = max(hi, e[2 * b + 1]); }
-    int zlo = 0;
-    if (L.bext) {
-        const int32_t* be = L.bext + ((int64_t)cat * L.n_col_tiles + ct) * 2;
-        lo = max(lo, be[0]);
-        hi = min(hi, be[1]);
-        if (be[1] >= be[0]) zlo = be[0];
+// Tile t of XCD `xcd`'s list -- the concatenation of the lists of the launch's ops, each pair-major with the row tile
+// fastest (the order prune_gemm.hip's decode assumes) -- as a plan entry: x = op << 24 | index in the op's own list,
+// y = first K tile << 16 | K tiles.  s_first[o]: where op o's tiles start in the XCD's list (s_first[n_ops] = all).
+__device__ inline int2 plan_tile_entry(const PlanLaunch& L, const int* s_first, int xcd, int t) {
+    int op = 0;
+    while (op + 1 < L.n_ops && t >= s_first[op + 1]) ++op;
+    const GemmOp& o = L.ops[op];
+    const int tl = t - s_first[op];
+    const int nrt = o.n_row_tiles, nct = L.uniform_ld > 0 ? L.uniform_ld / kBN : o.n_col_tiles;
+    const int row_tile = tl % nrt;
+    const int pair = xcd + 8 * (tl / nrt);
+    const int ct = pair % nct, cat = pair / nct;
+    int lo = 0, hi = L.k_valid - 1, zlo = 0;
+    if (L.aext) {
+        const int b0 = row_tile * L.mi;
+        const int32_t* e = L.aext + ((int64_t)o.slot[cat] * L.ext_blocks + b0) * 2;
+        lo = 0x7fffffff; hi = -1;
+        for (int b = 0; b < L.mi; ++b)
+            if (b0 + b < L.ext_blocks) { lo = min(lo, e[2 * b]); hi = max(hi, e[2 * b + 1]); }
+        if (o.bext) {
+            // (rows of B outside its tile extent may never have been written: the assemble pass leaves them out, leaf_reduce.hip)
+            const int32_t* be = o.bext + ((int64_t)cat * nct + ct) * 2;
+            lo = max(lo, be[0]);
+            hi = min(hi, be[1]);
+            if (be[1] >= be[0]) zlo = be[0];
+        }
+        if (hi < lo) { lo = zlo; hi = zlo; }               // an all-zero tile still runs one K tile: the panel must receive its zeros
+        hi = min(hi, L.k_valid - 1);
     }
-    if (hi < lo) { lo = zlo; hi = zlo; }
-    hi = min(hi, L.k_valid - 1);
-    kt0 = lo / kBK;
-    nkt = hi / kBK - lo / kBK + 1;
+    return make_int2((op << 24) | tl, ((lo / kBK) << 16) | (hi / kBK - lo / kBK + 1));
 }
 
 // The last kPlanTail rounds are dealt as ONE batch, longest tile first, each to the workgroup with the least load at that
@@ -108,11 +117,21 @@ __global__ __launch_bounds__(64) void tile_plan_kernel(const PlanLaunch* __restr
     const PlanLaunch& L = launches[blockIdx.y];
     const int xcd = blockIdx.x, lane = threadIdx.x;
     const int nlb = L.blocks_per_xcd;
-    const int my_pairs = (L.n_categories * L.n_col_tiles - xcd + 7) >> 3;
-    const int n_tiles = my_pairs * L.n_row_tiles;
+    __shared__ int s_first[kMaxGroupOps + 1];
+    if (lane == 0) {
+        int acc = 0;
+        for (int o = 0; o < L.n_ops; ++o) {
+            s_first[o] = acc;
+            const int nct = L.uniform_ld > 0 ? L.uniform_ld / kBN : L.ops[o].n_col_tiles;
+            acc += ((L.n_categories * nct - xcd + 7) >> 3) * L.ops[o].n_row_tiles;
+        }
+        s_first[L.n_ops] = acc;
+    }
+    __syncthreads();
+    const int n_tiles = s_first[L.n_ops];
     const int weight = (nlb == 64 && L.bias) ? (lane < 32 ? 100 - L.bias : 100 + L.bias) : 100;   // of this lane's workgroup
     __shared__ int s_load[64], s_cost[64], s_who[64];
-    __shared__ int t_cost[kPlanTail * 64], t_y[kPlanTail * 64], t_by_rank[kPlanTail * 64];
+    __shared__ int t_cost[kPlanTail * 64], t_x[kPlanTail * 64], t_y[kPlanTail * 64], t_by_rank[kPlanTail * 64];
     s_load[lane] = 0;
     __syncthreads();
     const int head = max(0, (n_tiles + nlb - 1) / nlb - kPlanTail);      // full rounds dealt one by one
@@ -120,9 +139,9 @@ __global__ __launch_bounds__(64) void tile_plan_kernel(const PlanLaunch* __restr
     for (int r = 0; r < head; ++r) {
         const int t = r * nlb + lane;
         const bool valid = lane < nlb;
-        int kt0 = 0, nkt = 0;
-        if (valid) plan_tile_range(L, xcd, t, kt0, nkt);
-        const int cst = valid ? nkt + L.fixed : -1;
+        int2 en = make_int2(0, 0);
+        if (valid) en = plan_tile_entry(L, s_first, xcd, t);
+        const int cst = valid ? (en.y & 0xFFFF) + L.fixed : -1;
         const int mine = s_load[lane];
         s_cost[lane] = cst;
         __syncthreads();
@@ -136,7 +155,7 @@ __global__ __launch_bounds__(64) void tile_plan_kernel(const PlanLaunch* __restr
         __syncthreads();
         if (valid) {
             const int w = s_who[crank];
-            L.plan[((int64_t)xcd * nlb + w) * L.rounds + r] = make_int2(t, (kt0 << 16) | nkt);
+            L.plan[((int64_t)xcd * nlb + w) * L.rounds + r] = en;
             const int ww = (nlb == 64 && L.bias) ? (w < 32 ? 100 - L.bias : 100 + L.bias) : 100;
             s_load[w] += cst * ww;
         }
@@ -145,10 +164,10 @@ __global__ __launch_bounds__(64) void tile_plan_kernel(const PlanLaunch* __restr
     // ---- the rest as one batch
     const int t0 = head * nlb, n_tail = n_tiles - t0;
     for (int i = lane; i < n_tail; i += 64) {
-        int kt0, nkt;
-        plan_tile_range(L, xcd, t0 + i, kt0, nkt);
-        t_cost[i] = nkt + L.fixed;
-        t_y[i] = (kt0 << 16) | nkt;
+        const int2 en = plan_tile_entry(L, s_first, xcd, t0 + i);
+        t_cost[i] = (en.y & 0xFFFF) + L.fixed;
+        t_x[i] = en.x;
+        t_y[i] = en.y;
     }
     __syncthreads();
     for (int i = lane; i < n_tail; i += 64) {
@@ -165,7 +184,7 @@ __global__ __launch_bounds__(64) void tile_plan_kernel(const PlanLaunch* __restr
         unsigned key = (lane < nlb && pos < L.rounds) ? ((min(load, 0x01FFFFFFu) << 6) | (unsigned)lane) : 0xFFFFFFFFu;
         for (int off = 32; off > 0; off >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, off));
         if (key != 0xFFFFFFFFu && lane == (int)(key & 63u)) {
-            mylist[pos++] = make_int2(t0 + item, t_y[item]);
+            mylist[pos++] = make_int2(t_x[item], t_y[item]);
             load += (unsigned)(t_cost[item] * weight);
         }
     }

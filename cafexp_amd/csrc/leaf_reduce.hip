@@ -9,63 +9,76 @@
 //
 // K4 replaces the per-family tail of base_model::infer_family_likelihoods (src/base_model.cpp:89-106)
 // and gamma_model::prune / infer_family_likelihoods (src/gamma_core.cpp:144-166, 201-225).
+#include <algorithm>
+
 #include "cafe_kernels.h"
 
 namespace cafe {
 
 constexpr int kGatherRows = 16;   // rows of the panel per block
 
-__global__ __launch_bounds__(256) void leaf_gather_kernel(const GatherArgs a) {
-    const int cat = blockIdx.z;
+// A K3 launch carries a GROUP of ops of one variant (the ready nodes of a tree level): blockIdx.z = op * K + category; the
+// grid is as wide and as tall as the group's largest op, blocks beyond an op's own extent return at once.  The op
+// descriptors live in a device array, read-only for the launch (constant address space: wave-uniform scalar loads).
+typedef const __attribute__((address_space(4))) GatherArgs* gop_cptr_t;
+#define CAFE_GATHER_OP()                                                                   \
+    const int op_index = blockIdx.z / g.n_categories, cat = blockIdx.z - op_index * g.n_categories; \
+    const gop_cptr_t a = (gop_cptr_t)(unsigned long long)g.ops + op_index;              \
+    const int ld = g.uniform_ld > 0 ? g.uniform_ld : a->ld
+
+__global__ __launch_bounds__(256) void leaf_gather_kernel(const GatherGroup g) {
+    CAFE_GATHER_OP();
     const int f = blockIdx.x * 256 + threadIdx.x;           // column inside the chunk (ld is a multiple of 128)
-    if (f >= a.ld) return;
+    if (f >= ld) return;
     const int r0 = blockIdx.y * kGatherRows;
-    double* __restrict__ dst = a.dst + (int64_t)cat * a.panel_kstride + f;
-    const int ldp = a.pool.ld;
+    if (r0 >= a->rows_store) return;
+    double* __restrict__ dst = a->dst + (int64_t)cat * a->panel_kstride + f;
+    const int ldp = g.pool.ld;
+    const int n_leaf = a->n_leaf, n_src = a->n_src, rows = a->rows, rows_store = a->rows_store, row_off = a->row_off, mode = a->mode;
 
     int x[kMaxLeafPerOp];
     const double* P[kMaxLeafPerOp];
 #pragma unroll
     for (int l = 0; l < kMaxLeafPerOp; ++l) {
-        if (l < a.n_leaf) {
-            x[l] = a.counts[(int64_t)a.taxon[l] * a.counts_ld + a.f0 + f];
-            P[l] = a.pool.base + (int64_t)a.slot[l][cat] * a.pool.stride;
+        if (l < n_leaf) {
+            x[l] = a->counts[(int64_t)a->taxon[l] * a->counts_ld + g.f0 + f];
+            P[l] = g.pool.base + (int64_t)a->slot[l][cat] * g.pool.stride;
         } else {
             x[l] = 0;
-            P[l] = a.pool.base;
+            P[l] = g.pool.base;
         }
     }
-    const int half = (a.n_dev - 1) / 2;
+    const int half = (g.n_dev - 1) / 2;
 
     for (int rr = 0; rr < kGatherRows; ++rr) {
         const int r = r0 + rr;
-        if (r >= a.rows_store) break;
+        if (r >= rows_store) break;
         double v = 0.0;
-        if (r < a.rows) {
-            const int64_t srow = (int64_t)(r + a.row_off) * ldp;
+        if (r < rows) {
+            const int64_t srow = (int64_t)(r + row_off) * ldp;
             v = 1.0;
 #pragma unroll
             for (int l = 0; l < kMaxLeafPerOp; ++l) {
-                if (l < a.n_leaf) {
+                if (l < n_leaf) {
                     double fac;
-                    if (a.err == nullptr) {
+                    if (g.err == nullptr) {
                         fac = P[l][srow + x[l]];
                     } else {
                         fac = 0.0;
-                        for (int i = 0; i < a.n_dev; ++i) {
+                        for (int i = 0; i < g.n_dev; ++i) {
                             const int c = x[l] - half + i;
-                            if (c < 0 || c > a.max_family_size) continue;
-                            fac += P[l][srow + c] * a.err[(int64_t)x[l] * a.n_dev + i];
+                            if (c < 0 || c > g.max_family_size) continue;
+                            fac += P[l][srow + c] * g.err[(int64_t)x[l] * g.n_dev + i];
                         }
                     }
                     v *= fac;
                 }
             }
-            for (int j = 0; j < a.n_src; ++j)           // transposed factors: [column][15 + row_off + panel row]
-                v *= a.src[j][(int64_t)cat * a.panel_kstride + (int64_t)a.map[j][f] * a.ld_src[j] + 15 + a.row_off + r];
-            if (a.mode) v *= dst[(int64_t)r * a.ld];
+            for (int j = 0; j < n_src; ++j)             // transposed factors: [column][15 + row_off + panel row]
+                v *= a->src[j][(int64_t)cat * a->kstride_src[j] + (int64_t)a->map[j][f] * a->ld_src[j] + 15 + row_off + r];
+            if (mode) v *= dst[(int64_t)r * ld];
         }
-        dst[(int64_t)r * a.ld] = v;
+        dst[(int64_t)r * ld] = v;
     }
 }
 
@@ -76,59 +89,64 @@ __global__ __launch_bounds__(256) void leaf_gather_kernel(const GatherArgs a) {
 // (probability.cpp:187-196 builds the leaf vector, matrix_cache.cpp:28 multiplies it).
 constexpr int kFastRows = 8;
 template <int NLEAF, int NDEV, bool MUL, int NSRC>
-__global__ __launch_bounds__(256) void leaf_gather_fast_kernel(const GatherArgs a) {
-    const int cat = blockIdx.z;
+__global__ __launch_bounds__(256) void leaf_gather_fast_kernel(const GatherGroup g) {
+    CAFE_GATHER_OP();
     const int f = (blockIdx.x * 256 + threadIdx.x) * 2;
-    if (f >= a.ld) return;
+    if (f >= ld) return;
     const int r0 = blockIdx.y * kFastRows;
-    if (a.tileext) {
+    const int rows = a->rows, rows_store = a->rows_store;
+    if (r0 >= rows_store) return;
+    if (a->tileext) {
         // rows outside the zero extents of the workgroup's (up to four) 128-column tiles are never staged by K2 (see the
         // assemble pass below): leave them as they are
-        const int n_ct = a.ld / kBN, ct0 = (blockIdx.x * 512) / kBN;
+        const int n_ct = ld / kBN, ct0 = (blockIdx.x * 512) / kBN;
         int lo = 0x7fffffff, hi = -1;
         for (int ct = ct0; ct < ct0 + 4 && ct < n_ct; ++ct) {
-            const int32_t* te = a.tileext + ((int64_t)cat * n_ct + ct) * 2;
+            const int32_t* te = a->tileext + ((int64_t)cat * n_ct + ct) * 2;
             const bool some = te[1] >= te[0];
             lo = min(lo, some ? te[0] : 0);
             hi = max(hi, some ? te[1] : 0);
         }
         if (r0 + kFastRows - 1 < (lo & ~15) || r0 > (hi | 15)) return;
     }
-    const unsigned ldp = (unsigned)a.pool.ld;
-    double* __restrict__ dst = a.dst + (int64_t)cat * a.panel_kstride + (int64_t)r0 * a.ld + f;
+    const unsigned ldp = (unsigned)g.pool.ld;
+    double* __restrict__ dst = a->dst + (int64_t)cat * a->panel_kstride + (int64_t)r0 * ld + f;
     constexpr int NL = NLEAF > 0 ? NLEAF : 1;               // (zero-length arrays are not allowed)
     unsigned o0[NL][NDEV], o1[NL][NDEV];
     double w0[NL][NDEV], w1[NL][NDEV];
     const double* P[NL];
     const double* S[NSRC > 0 ? NSRC : 1];                   // factor panels, row r0 of this category
     unsigned m0[NSRC > 0 ? NSRC : 1], m1[NSRC > 0 ? NSRC : 1];
+    int64_t lds_[NSRC > 0 ? NSRC : 1];
 #pragma unroll
     for (int j = 0; j < NSRC; ++j) {
-        S[j] = a.src[j] + (int64_t)cat * a.panel_kstride + (int64_t)r0 * a.ld_src[j];
-        m0[j] = (unsigned)a.map[j][f];
-        m1[j] = (unsigned)a.map[j][f + 1];
+        lds_[j] = a->ld_src[j];
+        S[j] = a->src[j] + (int64_t)cat * a->kstride_src[j] + (int64_t)r0 * lds_[j];
+        m0[j] = (unsigned)a->map[j][f];
+        m1[j] = (unsigned)a->map[j][f + 1];
     }
     constexpr int half = (NDEV - 1) / 2;
+    const int row_off = a->row_off;
 #pragma unroll
     for (int l = 0; l < NLEAF; ++l) {
-        const int32_t* cnt = a.counts + (int64_t)a.taxon[l] * a.counts_ld + a.f0 + f;
+        const int32_t* cnt = a->counts + (int64_t)a->taxon[l] * a->counts_ld + g.f0 + f;
         const int x0 = cnt[0], x1 = cnt[1];
 #pragma unroll
         for (int i = 0; i < NDEV; ++i) {
             const int c0 = x0 - half + i, c1 = x1 - half + i;
-            const bool ok0 = c0 >= 0 && c0 <= a.max_family_size, ok1 = c1 >= 0 && c1 <= a.max_family_size;
+            const bool ok0 = c0 >= 0 && c0 <= g.max_family_size, ok1 = c1 >= 0 && c1 <= g.max_family_size;
             o0[l][i] = (unsigned)(ok0 ? c0 : x0);
             o1[l][i] = (unsigned)(ok1 ? c1 : x1);
-            w0[l][i] = NDEV == 1 ? 1.0 : (ok0 ? a.err[(int64_t)x0 * NDEV + i] : 0.0);
-            w1[l][i] = NDEV == 1 ? 1.0 : (ok1 ? a.err[(int64_t)x1 * NDEV + i] : 0.0);
+            w0[l][i] = NDEV == 1 ? 1.0 : (ok0 ? g.err[(int64_t)x0 * NDEV + i] : 0.0);
+            w1[l][i] = NDEV == 1 ? 1.0 : (ok1 ? g.err[(int64_t)x1 * NDEV + i] : 0.0);
         }
-        P[l] = a.pool.base + (int64_t)a.slot[l][cat] * a.pool.stride + (int64_t)(r0 + a.row_off) * ldp;
+        P[l] = g.pool.base + (int64_t)a->slot[l][cat] * g.pool.stride + (int64_t)(r0 + row_off) * ldp;
     }
     double2 v[kFastRows];
 #pragma unroll
     for (int rr = 0; rr < kFastRows; ++rr) {
         v[rr] = make_double2(0.0, 0.0);
-        if (r0 + rr < a.rows) {
+        if (r0 + rr < rows) {
             double x = 1.0, y = 1.0;
 #pragma unroll
             for (int l = 0; l < NLEAF; ++l) {
@@ -149,12 +167,12 @@ __global__ __launch_bounds__(256) void leaf_gather_fast_kernel(const GatherArgs 
             }
 #pragma unroll
             for (int j = 0; j < NSRC; ++j) {
-                const double* row = S[j] + (int64_t)rr * a.ld_src[j];
+                const double* row = S[j] + (int64_t)rr * lds_[j];
                 x *= row[m0[j]];
                 y *= row[m1[j]];
             }
             if (MUL) {
-                const double2 old = *reinterpret_cast<const double2*>(dst + (int64_t)rr * a.ld);
+                const double2 old = *reinterpret_cast<const double2*>(dst + (int64_t)rr * ld);
                 x *= old.x;
                 y *= old.y;
             }
@@ -163,21 +181,21 @@ __global__ __launch_bounds__(256) void leaf_gather_fast_kernel(const GatherArgs 
     }
 #pragma unroll
     for (int rr = 0; rr < kFastRows; ++rr)
-        if (r0 + rr < a.rows_store) {
+        if (r0 + rr < rows_store) {
             // streamed once, read back by the next GEMM from HBM anyway: do not displace the matrices in L2
-            __builtin_nontemporal_store(v[rr].x, dst + (int64_t)rr * a.ld);
-            __builtin_nontemporal_store(v[rr].y, dst + (int64_t)rr * a.ld + 1);
+            __builtin_nontemporal_store(v[rr].x, dst + (int64_t)rr * ld);
+            __builtin_nontemporal_store(v[rr].y, dst + (int64_t)rr * ld + 1);
         }
 }
 
 template <int NLEAF, int NDEV, int NSRC>
-static void launch_fast3(const GatherArgs& a, dim3 grid, hipStream_t stream) {
-    if (a.mode) hipLaunchKernelGGL((leaf_gather_fast_kernel<NLEAF, NDEV, true, NSRC>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((leaf_gather_fast_kernel<NLEAF, NDEV, false, NSRC>), grid, dim3(256), 0, stream, a);
+static void launch_fast3(const GatherGroup& g, int mode, dim3 grid, hipStream_t stream) {
+    if (mode) hipLaunchKernelGGL((leaf_gather_fast_kernel<NLEAF, NDEV, true, NSRC>), grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((leaf_gather_fast_kernel<NLEAF, NDEV, false, NSRC>), grid, dim3(256), 0, stream, g);
 }
 template <int NLEAF, int NDEV>
-static void launch_fast(const GatherArgs& a, dim3 grid, hipStream_t stream) {
-    launch_fast3<NLEAF, NDEV, 0>(a, grid, stream);
+static void launch_fast(const GatherGroup& g, int mode, dim3 grid, hipStream_t stream) {
+    launch_fast3<NLEAF, NDEV, 0>(g, mode, grid, stream);
 }
 
 // Assemble pass: the parent's panel from the TRANSPOSED factor panels of its de-duplicated interior children (and its
@@ -190,17 +208,20 @@ static void launch_fast(const GatherArgs& a, dim3 grid, hipStream_t stream) {
 constexpr int kAsmT = 64;                   // tile: 64 columns x 64 rows of the transposed index space
 constexpr int kAsmS = kAsmT + 1;            // LDS row stride (doubles): column-wise reads of a row-major tile without conflicts
 template <int NSRC, int NLEAF, int NDEV, bool MUL>
-__global__ __launch_bounds__(256) void assemble_t_kernel(const GatherArgs a) {
+__global__ __launch_bounds__(256) void assemble_t_kernel(const GatherGroup g) {
     __shared__ double tile[kAsmT * kAsmS];
-    const int cat = blockIdx.z;
+    CAFE_GATHER_OP();
     const int c0 = blockIdx.x * kAsmT;                       // first parent column of the tile (ld is a multiple of 128)
+    if (c0 >= ld) return;
     const int i0 = blockIdx.y * kAsmT;                       // first transposed row index: panel row = index - toff
-    const int toff = 15 + a.row_off;
+    const int row_off = a->row_off, rows = a->rows, rows_store = a->rows_store;
+    const int toff = 15 + row_off;
+    if (i0 - toff >= rows_store) return;
     const int tid = threadIdx.x;
-    if (a.tileext) {
+    if (a->tileext) {
         // Rows outside the zero extent of the 128-column tile (extents.hip) are exact zeros that K2 never reads: it stages only
         // the K tiles (16 rows each) that meet the extent, or the tile at its first row when nothing does.  Leave them alone.
-        const int32_t* te = a.tileext + ((int64_t)cat * (a.ld / kBN) + (c0 / kBN)) * 2;
+        const int32_t* te = a->tileext + ((int64_t)cat * (ld / kBN) + (c0 / kBN)) * 2;
         int lo = te[0], hi = te[1];
         if (hi < lo) { lo = 0; hi = 0; }
         if (i0 + kAsmT - 1 - toff < (lo & ~15) || i0 - toff > (hi | 15)) return;
@@ -214,8 +235,8 @@ __global__ __launch_bounds__(256) void assemble_t_kernel(const GatherArgs a) {
             double2 v = make_double2(1.0, 1.0);
 #pragma unroll
             for (int j = 0; j < NSRC; ++j) {
-                const double2 f = *reinterpret_cast<const double2*>(a.src[j] + (int64_t)cat * a.panel_kstride +
-                                                                    (int64_t)a.map[j][c0 + c] * a.ld_src[j] + i0 + 2 * seg);
+                const double2 f = *reinterpret_cast<const double2*>(a->src[j] + (int64_t)cat * a->kstride_src[j] +
+                                                                    (int64_t)a->map[j][c0 + c] * a->ld_src[j] + i0 + 2 * seg);
                 v.x *= f.x;
                 v.y *= f.y;
             }
@@ -234,27 +255,27 @@ __global__ __launch_bounds__(256) void assemble_t_kernel(const GatherArgs a) {
     const double* P[NL];
 #pragma unroll
     for (int l = 0; l < NLEAF; ++l) {
-        const int x = a.counts[(int64_t)a.taxon[l] * a.counts_ld + a.f0 + f];
+        const int x = a->counts[(int64_t)a->taxon[l] * a->counts_ld + g.f0 + f];
 #pragma unroll
         for (int i = 0; i < NDEV; ++i) {
             const int c = x - half + i;
-            const bool ok = c >= 0 && c <= a.max_family_size;
+            const bool ok = c >= 0 && c <= g.max_family_size;
             o[l][i] = (unsigned)(ok ? c : x);
-            wgt[l][i] = NDEV == 1 ? 1.0 : (ok ? a.err[(int64_t)x * NDEV + i] : 0.0);
+            wgt[l][i] = NDEV == 1 ? 1.0 : (ok ? g.err[(int64_t)x * NDEV + i] : 0.0);
         }
-        P[l] = a.pool.base + (int64_t)a.slot[l][cat] * a.pool.stride;
+        P[l] = g.pool.base + (int64_t)a->slot[l][cat] * g.pool.stride;
     }
-    double* __restrict__ dst = a.dst + (int64_t)cat * a.panel_kstride + f;
+    double* __restrict__ dst = a->dst + (int64_t)cat * a->panel_kstride + f;
 #pragma unroll 4
     for (int rr = 0; rr < 16; ++rr) {
         const int r = i0 + 16 * w + rr - toff;               // panel row
-        if (r < 0 || r >= a.rows_store) continue;
+        if (r < 0 || r >= rows_store) continue;
         double v = 0.0;
-        if (r < a.rows) {
+        if (r < rows) {
             v = tile[lane * kAsmS + 16 * w + rr];
 #pragma unroll
             for (int l = 0; l < NLEAF; ++l) {
-                const double* row = P[l] + (int64_t)(r + a.row_off) * a.pool.ld;
+                const double* row = P[l] + (int64_t)(r + row_off) * g.pool.ld;
                 if (NDEV == 1) {
                     v *= row[o[l][0]];
                 } else {
@@ -264,43 +285,55 @@ __global__ __launch_bounds__(256) void assemble_t_kernel(const GatherArgs a) {
                     v *= fx;
                 }
             }
-            if (MUL) v *= dst[(int64_t)r * a.ld];
+            if (MUL) v *= dst[(int64_t)r * ld];
         }
-        __builtin_nontemporal_store(v, dst + (int64_t)r * a.ld);
+        __builtin_nontemporal_store(v, dst + (int64_t)r * ld);
     }
 }
 
 template <int NSRC, int NLEAF, int NDEV>
-static void launch_asm3(const GatherArgs& a, dim3 grid, hipStream_t stream) {
-    if (a.mode) hipLaunchKernelGGL((assemble_t_kernel<NSRC, NLEAF, NDEV, true>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((assemble_t_kernel<NSRC, NLEAF, NDEV, false>), grid, dim3(256), 0, stream, a);
+static void launch_asm3(const GatherGroup& g, int mode, dim3 grid, hipStream_t stream) {
+    if (mode) hipLaunchKernelGGL((assemble_t_kernel<NSRC, NLEAF, NDEV, true>), grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((assemble_t_kernel<NSRC, NLEAF, NDEV, false>), grid, dim3(256), 0, stream, g);
 }
 template <int NSRC>
-static void launch_asm(const GatherArgs& a, int ndev, dim3 grid, hipStream_t stream) {
-    if (a.n_leaf == 0) launch_asm3<NSRC, 0, 1>(a, grid, stream);
-    else if (a.n_leaf == 1) { if (ndev == 1) launch_asm3<NSRC, 1, 1>(a, grid, stream); else launch_asm3<NSRC, 1, 3>(a, grid, stream); }
-    else { if (ndev == 1) launch_asm3<NSRC, 2, 1>(a, grid, stream); else launch_asm3<NSRC, 2, 3>(a, grid, stream); }
+static void launch_asm(const GatherGroup& g, int n_leaf, int mode, int ndev, dim3 grid, hipStream_t stream) {
+    if (n_leaf == 0) launch_asm3<NSRC, 0, 1>(g, mode, grid, stream);
+    else if (n_leaf == 1) { if (ndev == 1) launch_asm3<NSRC, 1, 1>(g, mode, grid, stream); else launch_asm3<NSRC, 1, 3>(g, mode, grid, stream); }
+    else { if (ndev == 1) launch_asm3<NSRC, 2, 1>(g, mode, grid, stream); else launch_asm3<NSRC, 2, 3>(g, mode, grid, stream); }
 }
 
-hipError_t launch_leaf_gather(const GatherArgs& a, int n_categories, hipStream_t stream) {
+// h_ops: the group's descriptors on the host (grid extents and the variant: every op of a group has the same n_leaf, n_src
+// and mode -- the schedule groups by them)
+hipError_t launch_leaf_gather_group(const GatherGroup& g, const GatherArgs* h_ops, hipStream_t stream) {
     (void)hipGetLastError();
-    if (a.n_leaf == 0 && a.n_src == 0) return hipErrorInvalidValue;
-    const int ndev = a.err == nullptr ? 1 : a.n_dev;
-    if ((ndev == 1 || ndev == 3) && a.n_leaf <= 2 && a.n_src >= 1 && a.n_src <= 2) {
-        dim3 grid(a.ld / kAsmT, (a.rows_store + 15 + a.row_off + kAsmT - 1) / kAsmT, n_categories);
-        if (a.n_src == 1) launch_asm<1>(a, ndev, grid, stream);
-        else launch_asm<2>(a, ndev, grid, stream);
+    if (g.n_ops < 1 || !g.ops || !h_ops) return hipErrorInvalidValue;
+    const int n_leaf = h_ops[0].n_leaf, n_src = h_ops[0].n_src, mode = h_ops[0].mode;
+    if (n_leaf == 0 && n_src == 0) return hipErrorInvalidValue;
+    int max_ld = 0, max_rows_store = 0, max_row_off = 0;
+    for (int i = 0; i < g.n_ops; ++i) {
+        if (h_ops[i].n_leaf != n_leaf || h_ops[i].n_src != n_src || h_ops[i].mode != mode) return hipErrorInvalidValue;
+        max_ld = std::max(max_ld, g.uniform_ld > 0 ? g.uniform_ld : h_ops[i].ld);
+        max_rows_store = std::max(max_rows_store, h_ops[i].rows_store);
+        max_row_off = std::max(max_row_off, h_ops[i].row_off);
+    }
+    const unsigned z = (unsigned)(g.n_ops * g.n_categories);
+    if (z > 65535u) return hipErrorInvalidValue;
+    const int ndev = g.err == nullptr ? 1 : g.n_dev;
+    if ((ndev == 1 || ndev == 3) && n_leaf <= 2 && n_src >= 1 && n_src <= 2) {
+        dim3 grid(max_ld / kAsmT, (max_rows_store + 15 + max_row_off + kAsmT - 1) / kAsmT, z);
+        if (n_src == 1) launch_asm<1>(g, n_leaf, mode, ndev, grid, stream);
+        else launch_asm<2>(g, n_leaf, mode, ndev, grid, stream);
         return hipGetLastError();
     }
-    if ((ndev == 1 || ndev == 3) && a.n_leaf <= 2 && a.n_src == 0) {
-        dim3 grid((a.ld / 2 + 255) / 256, (a.rows_store + kFastRows - 1) / kFastRows, n_categories);
-        if (a.n_leaf == 0) launch_fast<0, 1>(a, grid, stream);
-        else if (a.n_leaf == 1) { if (ndev == 1) launch_fast<1, 1>(a, grid, stream); else launch_fast<1, 3>(a, grid, stream); }
-        else { if (ndev == 1) launch_fast<2, 1>(a, grid, stream); else launch_fast<2, 3>(a, grid, stream); }
+    if ((ndev == 1 || ndev == 3) && n_leaf <= 2 && n_src == 0) {
+        dim3 grid((max_ld / 2 + 255) / 256, (max_rows_store + kFastRows - 1) / kFastRows, z);
+        if (n_leaf == 1) { if (ndev == 1) launch_fast<1, 1>(g, mode, grid, stream); else launch_fast<1, 3>(g, mode, grid, stream); }
+        else { if (ndev == 1) launch_fast<2, 1>(g, mode, grid, stream); else launch_fast<2, 3>(g, mode, grid, stream); }
         return hipGetLastError();
     }
-    dim3 grid((a.ld + 255) / 256, (a.rows_store + kGatherRows - 1) / kGatherRows, n_categories), block(256);
-    hipLaunchKernelGGL(leaf_gather_kernel, grid, block, 0, stream, a);
+    dim3 grid((max_ld + 255) / 256, (max_rows_store + kGatherRows - 1) / kGatherRows, z), block(256);
+    hipLaunchKernelGGL(leaf_gather_kernel, grid, block, 0, stream, g);
     return hipGetLastError();
 }
 

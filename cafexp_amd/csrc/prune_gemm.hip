@@ -30,6 +30,7 @@
 //    per-lane offset, compile-time specialised epilogues, no per-element branches;
 //  * the accumulator array must only be indexed by compile-time constants, or it is demoted to
 //    scratch memory (5x slower).  `make check` fails the build if a K2 instantiation uses scratch.
+#include <algorithm>
 #include <type_traits>
 
 #include <hip/hip_ext.h>
@@ -39,6 +40,10 @@
 namespace cafe {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+// the op descriptors and tile lists are read-only for the launch: constant address space, so that a wave-uniform access is
+// a scalar load whatever the stores around it
+typedef const __attribute__((address_space(4))) GemmOp* op_cptr_t;
+typedef const __attribute__((address_space(4))) long long* plan_cptr_t;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -70,8 +75,8 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: LDS-DMA bases (M0) need no VALU
     const int l15 = lane & 15, l4 = lane >> 4;
     constexpr bool GATH = LEAF == 2;
-    const int lda = a.pool.ld, ldb = a.ld, ldl = GATH ? (int)a.gath_ld : a.lpool.ld;   // ldl: stride of what the epilogue gathers
-    const int ldt = a.dst_ldt;                                     // TRANS: rows per column of the transposed factor
+    const int lda = a.pool.ld;
+    const op_cptr_t ops = (op_cptr_t)(unsigned long long)a.ops;
     unsigned long long st0 = 0, ep_ticks = 0, n_done = 0;
     if (a.stamps) st0 = __builtin_amdgcn_s_memrealtime();
 
@@ -83,8 +88,6 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
     // (pair, row tile) couples, row tile fastest: the row tiles of one column tile run together and share the
     // child panel (B) in that L2.
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, n_local_blocks = gridDim.x >> 3;
-    const int my_pairs = (a.n_categories * a.n_col_tiles - xcd + 7) >> 3;    // pairs owned by this XCD
-    const int n_tiles = my_pairs * a.n_row_tiles;
 
     // per-lane constants that do not depend on the tile (tile origins travel in the scalar offsets)
     constexpr bool A_CONTIG = (SA == BM);
@@ -113,65 +116,46 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
     const int b_off = A_TILE + l4 * kBStride + wave * 32 + l15;
     const int n_k = (a.k_valid + kBK - 1) / kBK;
     const int last_steps = (a.k_valid - (n_k - 1) * kBK + 3) / 4;
-    const int kbytes = (int)(a.panel_kstride * 8 > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : a.panel_kstride * 8);
+    auto span_bytes = [](int64_t doubles) -> int { return (int)(doubles * 8 > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : doubles * 8); };
 
-    // Tile descriptor (all scalar): buffer resources of the A matrix / child panel / parent panel and origins
+    // Tile descriptor (all scalar): the op it belongs to, buffer resources of the A matrix / child panel / parent panel and
+    // origins.  K tiles [kt0, kt0 + nkt) are the ones inside (matrix extent of the row tile) x (panel extent of the column
+    // tile) -- worked out by the tile planner: far from the diagonal the matrix entries underflow to exact zeros, a likelihood
+    // column is exactly zero far from the observed sizes, and a K tile of zeros adds nothing: skipping it leaves every
+    // accumulator bit as it is and saves its MFMAs and the B rows it would have staged.  (An all-zero tile still runs one
+    // K tile: the panel must receive its zeros.)
     struct Tile {
         __amdgpu_buffer_rsrc_t rsA, rsB, rsC;
-        int cat, row0, col0, row_tile;
-        int kt0, nkt;                                       // K tiles [kt0, kt0 + nkt) hold this row tile's non-zero A entries
+        op_cptr_t o;
+        int cat, row0, col0, row_tile, ldb;
+        int kt0, nkt;
     };
-    const int32_t* __restrict__ ext = a.pool.ext;
-    // The workgroup's tiles: entry i of its planned list (tile_plan_kernel: x = index in the XCD's list, y = first K tile << 16
-    // | K tiles), or, without a plan, every n_local_blocks-th tile of the XCD's list (y = -1: the extent is worked out here).
-    // y == 0 ends the list.  All scalar.
-    const int2* __restrict__ mylist = a.plan ? a.plan + ((int64_t)xcd * n_local_blocks + local) * a.plan_rounds : nullptr;
+    // The workgroup's tiles: entry i of its planned list (tile_plan_kernel: x = op << 24 | index in the op's list for this
+    // XCD, y = first K tile << 16 | K tiles); y == 0 ends the list.  All scalar.
+    const plan_cptr_t mylist = (plan_cptr_t)(unsigned long long)(a.plan + ((int64_t)xcd * n_local_blocks + local) * a.plan_rounds);
     auto entry = [&](int i) -> int2 {
-        if (mylist) return i < a.plan_rounds ? mylist[i] : make_int2(0, 0);
-        const int t = local + i * n_local_blocks;
-        return t < n_tiles ? make_int2(t, -1) : make_int2(0, 0);
+        if (i >= a.plan_rounds) return make_int2(0, 0);
+        const long long e = mylist[i];                      // int2 {x, y}: x in the low word
+        return make_int2(__builtin_amdgcn_readfirstlane((int)(e & 0xFFFFFFFFll)), __builtin_amdgcn_readfirstlane((int)(e >> 32)));
     };
     auto decode = [&](int2 en) -> Tile {
-        const int t = en.x;
         Tile x;
-        x.row_tile = t % a.n_row_tiles;
-        const int pair = xcd + 8 * (t / a.n_row_tiles);
-        const int ct = pair % a.n_col_tiles;
-        x.cat = pair / a.n_col_tiles;
+        x.o = ops + (en.x >> 24);
+        const int t = en.x & 0xFFFFFF;
+        const int nrt = x.o->n_row_tiles;
+        x.ldb = a.uniform_ld > 0 ? a.uniform_ld : x.o->ld;
+        const int nct = x.ldb / kBN;
+        x.row_tile = t % nrt;
+        const int pair = xcd + 8 * (t / nrt);
+        const int ct = pair % nct;
+        x.cat = pair / nct;
         x.row0 = x.row_tile * BM;
         x.col0 = ct * kBN;
-        x.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.pool.base + (int64_t)a.slot[x.cat] * a.pool.stride), 0, (int)(a.pool.stride * 8), 0x00020000);
-        x.rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src + (int64_t)x.cat * a.panel_kstride), 0, kbytes, 0x00020000);
-        x.rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dst + (int64_t)x.cat * a.panel_kstride), 0, kbytes, 0x00020000);
-        // Extent of the contraction index over which this row tile's part of the matrix is not exactly zero (K1 records it
-        // per block of 16 rows): far from the diagonal the entries underflow to 0, and a K tile of zeros adds nothing --
-        // skipping it leaves every accumulator bit as it is and saves its MFMAs and the B rows it would have staged.
-        x.kt0 = 0;
-        x.nkt = n_k;
-        if (en.y != -1) {
-            x.kt0 = __builtin_amdgcn_readfirstlane(en.y >> 16);
-            x.nkt = __builtin_amdgcn_readfirstlane(en.y & 0xFFFF);
-        } else if (ext) {
-            const int b0 = x.row0 >> 4;
-            const int32_t* e = ext + ((int64_t)a.slot[x.cat] * a.pool.ext_blocks + b0) * 2;
-            int lo = 0x7fffffff, hi = -1;
-#pragma unroll
-            for (int b = 0; b < MI; ++b)
-                if (b0 + b < a.pool.ext_blocks) { lo = min(lo, e[2 * b]); hi = max(hi, e[2 * b + 1]); }
-            int zlo = 0;                                    // a K tile that is safe to run when nothing needs to be
-            if (a.bext) {                                   // and the rows of this column tile of B that are not all zero
-                const int32_t* be = a.bext + ((int64_t)x.cat * a.n_col_tiles + ct) * 2;
-                lo = max(lo, be[0]);
-                hi = min(hi, be[1]);
-                if (be[1] >= be[0]) zlo = be[0];            // (rows of B outside its tile extent may never have been written:
-                                                            // the assemble pass leaves them out, leaf_reduce.hip)
-            }
-            if (hi < lo) { lo = zlo; hi = zlo; }            // an all-zero tile still runs one K tile (every product in it has a
-                                                            // zero factor): the panel must receive its zeros
-            hi = min(hi, a.k_valid - 1);
-            x.kt0 = __builtin_amdgcn_readfirstlane(lo / kBK);
-            x.nkt = __builtin_amdgcn_readfirstlane(hi / kBK - lo / kBK + 1);
-        }
+        x.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.pool.base + (int64_t)x.o->slot[x.cat] * a.pool.stride), 0, (int)(a.pool.stride * 8), 0x00020000);
+        x.rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(x.o->src + (int64_t)x.cat * x.o->src_kstride), 0, span_bytes(x.o->src_kstride), 0x00020000);
+        x.rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(x.o->dst + (int64_t)x.cat * x.o->dst_kstride), 0, span_bytes(x.o->dst_kstride), 0x00020000);
+        x.kt0 = en.y >> 16;
+        x.nkt = en.y & 0xFFFF;
         return x;
     };
     // LDS-DMA fill of K tile k0 of output tile x into stage `buf`, quarter q (16 slots = 4 quarters x 4 waves).
@@ -193,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
             if (nl == 64 || lane < nl)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(x.rsA, (lptr_t)(As + krow * SA), 16, lane16, ((k0 + krow) * lda + x.row0) * 8, 0, 0);
         }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(x.rsB, (lptr_t)(Bs + krow * kBStride), 16, lane16, ((k0 + krow) * ldb + x.col0) * 8, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x.rsB, (lptr_t)(Bs + krow * kBStride), 16, lane16, ((k0 + krow) * x.ldb + x.col0) * 8, 0, 0);
     };
 
     int2 e_cur = entry(0);
@@ -316,8 +300,12 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
         // half) + one fixed per-lane offset -- no address VALU and no LDS round trip; the old panel values (MUL) and
         // the leaf factors (LEAF) of row block i+1 are loaded before block i is stored.
         // TRANS (accumulators hold C^T): lane & 15 = row inside the 16-row block, (lane >> 4) + 4 reg = column inside the 16
+        const op_cptr_t o = cur.o;
+        const int ldb = cur.ldb, ldt = o->dst_ldt;          // ldt (TRANS): rows per column of the transposed factor
+        const int ldl = GATH ? (int)o->gath_ld : a.lpool.ld;   // stride of what the epilogue gathers
+        const int out_off = o->out_off;
         const unsigned c_voff = TRANS ? (unsigned)(((wave * 32 + l4) * ldt + l15) * 8) : (unsigned)((l4 * ldb + wave * 32 + l15) * 8);
-        const int c_soff0 = TRANS ? (cur.col0 * ldt + cur.row0 + 16) * 8 : ((cur.row0 + a.out_off) * ldb + cur.col0) * 8;
+        const int c_soff0 = TRANS ? (cur.col0 * ldt + cur.row0 + 16) * 8 : ((cur.row0 + out_off) * ldb + cur.col0) * 8;
         __amdgpu_buffer_rsrc_t rsL = cur.rsC;
         constexpr int NT = LEAF == 3 ? 3 : 1;               // taps of the leaf sibling: 1, or the 3 of an error model
         unsigned l_voff[2][NT];
@@ -325,8 +313,8 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
         int l_soff0 = 0;
         if (GATH) {
             // sibling factor F[s][map[column]]: the same access shape as a leaf's matrix column, another base and stride
-            const int32_t* mp = a.gath_map + cur.col0 + wave * 32 + l15;
-            rsL = __builtin_amdgcn_make_buffer_rsrc((void*)(a.gath_src + (int64_t)cur.cat * a.panel_kstride), 0, kbytes, 0x00020000);
+            const int32_t* mp = o->gath_map + cur.col0 + wave * 32 + l15;
+            rsL = __builtin_amdgcn_make_buffer_rsrc((void*)(o->gath_src + (int64_t)cur.cat * o->gath_kstride), 0, span_bytes(o->gath_kstride), 0x00020000);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 l_voff[j][0] = (unsigned)((mp[16 * j] * ldl + l4) * 8);     // transposed factor: [column][16 - out_off + row]
@@ -334,8 +322,8 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
             }
             l_soff0 = (cur.row0 + 16) * 8;
         } else if (LEAF) {
-            const int32_t* cnt = a.counts + (int64_t)a.taxon[0] * a.counts_ld + a.f0 + cur.col0 + wave * 32 + l15;
-            rsL = __builtin_amdgcn_make_buffer_rsrc((void*)(a.lpool.base + (int64_t)a.leaf_slot[0][cur.cat] * a.lpool.stride), 0,
+            const int32_t* cnt = o->counts + (int64_t)o->taxon * o->counts_ld + a.f0 + cur.col0 + wave * 32 + l15;
+            rsL = __builtin_amdgcn_make_buffer_rsrc((void*)(a.lpool.base + (int64_t)o->leaf_slot[cur.cat] * a.lpool.stride), 0,
                                                     (int)(a.lpool.stride * 8), 0x00020000);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -350,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
             }
             l_soff0 = (cur.row0 + 1) * ldl * 8;             // parent size row0 + 1
         }
-        const int rows_here = a.rows - cur.row0;            // valid rows of this tile (>= BM for interior tiles)
+        const int rows_here = o->rows - cur.row0;           // valid rows of this tile (>= BM for interior tiles)
         struct Pre { double f[2][4]; };
         // FULL: the tile has all BM rows (always true when 16*MI divides the row count): no per-row masks
         auto prefetch = [&](int i, Pre& p, auto full) {
@@ -424,16 +412,16 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
         if (a.stamps) { ep_ticks += __builtin_amdgcn_s_memrealtime() - e0; n_done += 1; }
         // parent size 0 only reaches child size 0 (P[0][c] = delta(c,0)): that panel row is the child's row 0,
         // times the leaf sibling's P_leaf[0][x] = delta(x,0) (with an error model: the weight of the tap at size 0)
-        if (a.out_off == 1 && cur.row_tile == 0 && tid < kBN / 2) {
+        if (out_off == 1 && cur.row_tile == 0 && tid < kBN / 2) {
             const int c2 = tid * 2;
-            const double* Bp = a.src + (int64_t)cur.cat * a.panel_kstride + cur.col0 + c2;
+            const double* Bp = o->src + (int64_t)cur.cat * o->src_kstride + cur.col0 + c2;
             double2 v = *reinterpret_cast<const double2*>(Bp);
             if (GATH) {                                     // the sibling's factor at parent size 0 (transposed: row index 15)
-                const double* G = a.gath_src + (int64_t)cur.cat * a.panel_kstride + 15;
-                v.x *= G[(int64_t)a.gath_map[cur.col0 + c2] * ldl];
-                v.y *= G[(int64_t)a.gath_map[cur.col0 + c2 + 1] * ldl];
+                const double* G = o->gath_src + (int64_t)cur.cat * o->gath_kstride + 15;
+                v.x *= G[(int64_t)o->gath_map[cur.col0 + c2] * ldl];
+                v.y *= G[(int64_t)o->gath_map[cur.col0 + c2 + 1] * ldl];
             } else if (LEAF) {
-                const int32_t* cnt = a.counts + (int64_t)a.taxon[0] * a.counts_ld + a.f0 + cur.col0 + c2;
+                const int32_t* cnt = o->counts + (int64_t)o->taxon * o->counts_ld + a.f0 + cur.col0 + c2;
                 if (LEAF == 1) {
                     v.x = cnt[0] == 0 ? v.x : 0.0;
                     v.y = cnt[1] == 0 ? v.y : 0.0;
@@ -443,11 +431,11 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
                 }
             }
             if (TRANS) {
-                double* dt = a.dst + (int64_t)cur.cat * a.panel_kstride + (int64_t)(cur.col0 + c2) * ldt + 15;
+                double* dt = o->dst + (int64_t)cur.cat * o->dst_kstride + (int64_t)(cur.col0 + c2) * ldt + 15;
                 dt[0] = v.x;
                 dt[ldt] = v.y;
             } else {
-                double2* dst = reinterpret_cast<double2*>(a.dst + (int64_t)cur.cat * a.panel_kstride + cur.col0 + c2);
+                double2* dst = reinterpret_cast<double2*>(o->dst + (int64_t)cur.cat * o->dst_kstride + cur.col0 + c2);
                 if (MUL) {
                     const double2 old = *dst;
                     v.x *= old.x;
@@ -471,18 +459,16 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
 #endif
 }
 
-// Row-tile height (in 16-row blocks) of a launch: the persistent grid has `slots` workgroups, a launch takes
-// ceil(tiles / slots) rounds of one tile each, and a tile costs about MI (its MFMA count) -- so small launches (the
-// de-duplicated panels of cherries and small clades, or small shards) are better off with lower tiles that fill
-// their last round, while large ones want the tallest tile without row padding.  Lower tiles are a little less
-// efficient per flop (80-row tiles: 68.2 against 69.9 TFLOP/s on full-width launches): 0.6 % per step of MI.
-int prune_gemm_pick_mi(int rows, int n_col_tiles, int n_categories, int slots) {
+// Row-tile height (in 16-row blocks) of a launch without extent information: the persistent grid has `slots` workgroups, a
+// launch takes ceil(tiles / slots) rounds of one tile each, and a tile costs about MI (its MFMA count) -- so small launches
+// are better off with lower tiles that fill their last round, while large ones want the tallest tile without row padding.
+// Lower tiles are a little less efficient per flop (80-row tiles: 68.2 against 69.9 TFLOP/s on full-width launches): 0.6 %
+// per step of MI.  tiles_by_mi[mi]: tiles of the whole group at that height.
+int prune_gemm_pick_mi(int64_t tiles_by_mi[10], int slots) {
     int best = 9;
     double best_cost = 1e300;
     for (int mi = 9; mi >= 4; --mi) {
-        const int64_t row_tiles = (rows + 16 * mi - 1) / (16 * mi);
-        const int64_t tiles = row_tiles * n_col_tiles * n_categories;
-        const int64_t rounds = (tiles + slots - 1) / slots;
+        const int64_t rounds = (tiles_by_mi[mi] + slots - 1) / slots;
         const double cost = (double)rounds * mi * (1.0 + 0.006 * (9 - mi));
         if (cost < best_cost * (1.0 - 1e-9)) { best_cost = cost; best = mi; }
     }
@@ -490,14 +476,12 @@ int prune_gemm_pick_mi(int rows, int n_col_tiles, int n_categories, int slots) {
 }
 
 // Persistent grid: two workgroups per CU (what the register/LDS budget admits), a multiple of 8 so that every XCD gets the
-// same number.  XCD x (blocks x, x+8, ...) owns the (category, column tile) pairs x, x+8, ... and its blocks share those
-// pairs' row tiles: a small launch needs ceil(pairs / 8) * n_row_tiles blocks PER XCD or the owning XCD's few blocks walk
-// the row tiles one after the other while the other XCDs' blocks have nothing to do.
-int prune_gemm_blocks(int n_categories, int n_col_tiles, int n_row_tiles, int n_cu) {
-    int blocks = 2 * n_cu / 8 * 8;
-    const int64_t per_xcd = (((int64_t)n_categories * n_col_tiles + 7) / 8) * n_row_tiles;
-    if (per_xcd * 8 < blocks) blocks = (int)(per_xcd * 8);
-    return blocks;
+// same number.  XCD x (blocks x, x+8, ...) owns the (category, column tile) pairs x, x+8, ... of every op of the launch and
+// its blocks share those pairs' row tiles: a small launch gets as many blocks per XCD as the busiest XCD (XCD 0) has tiles.
+int prune_gemm_blocks(int64_t tiles_xcd0, int n_cu) {
+    int blocks = std::min(2 * n_cu / 8 * 8, 512);        // (the planner deals with one lane per workgroup of an XCD: at most 64)
+    if (tiles_xcd0 * 8 < blocks) blocks = (int)(tiles_xcd0 * 8);
+    return blocks < 8 ? 8 : blocks;
 }
 
 // ev0 / ev1 (both or neither): start / stop events attached to the dispatch itself (hipExtLaunchKernelGGL) -- the per-launch
@@ -508,18 +492,18 @@ int prune_gemm_blocks(int n_categories, int n_col_tiles, int n_row_tiles, int n_
         else hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, stream, a);                               \
     } while (0)
 template <int MI>
-static void launch_mi(const GemmArgs& a, dim3 grid, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+static void launch_mi(const GemmArgs& a, GemmVariant v, dim3 grid, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     const dim3 block(256);
-    const int leaf = a.n_leaf ? (a.err ? 3 : 1) : (a.gath_src ? 2 : 0);
+    const int leaf = v.leaf == 1 ? (a.err ? 3 : 1) : v.leaf;
     if (leaf == 2) {                                       // gathered sibling factor: always the launch that creates the panel
         CAFE_LAUNCH_GEMM(prune_gemm_kernel<MI, false, 2>);
         return;
     }
-    if (a.dst_ldt) {                                       // factor GEMM: transposed plain store
+    if (v.trans) {                                         // factor GEMM: transposed plain store
         CAFE_LAUNCH_GEMM(prune_gemm_kernel<MI, false, 0, true>);
         return;
     }
-    if (a.mode) {
+    if (v.mode) {
         if (leaf == 3) CAFE_LAUNCH_GEMM(prune_gemm_kernel<MI, true, 3>);
         else if (leaf == 1) CAFE_LAUNCH_GEMM(prune_gemm_kernel<MI, true, 1>);
         else CAFE_LAUNCH_GEMM(prune_gemm_kernel<MI, true, 0>);
@@ -530,27 +514,19 @@ static void launch_mi(const GemmArgs& a, dim3 grid, hipStream_t stream, hipEvent
     }
 }
 
-hipError_t launch_prune_gemm(const GemmArgs& a_in, int n_categories, int n_cu, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-    if (a_in.n_leaf > 1 || (a_in.n_leaf == 1 && a_in.err != nullptr && a_in.n_dev != 3)) return hipErrorInvalidValue;   // the schedule never asks for it
-    if (a_in.gath_src && (a_in.n_leaf || a_in.mode || !a_in.gath_map || a_in.dst_ldt)) return hipErrorInvalidValue;
-    if (a_in.dst_ldt && (a_in.n_leaf || a_in.mode)) return hipErrorInvalidValue;
-    GemmArgs a = a_in;
-    a.n_categories = n_categories;
-    if (n_cu < 8) return hipErrorInvalidValue;
-    if (a.mi == 0) {                                       // the caller leaves the tile height to the launcher
-        if (a.plan) return hipErrorInvalidValue;           // (a plan is laid out for one tile height)
-        a.mi = prune_gemm_pick_mi(a.rows, a.n_col_tiles, n_categories, 2 * n_cu / 8 * 8);
-        a.n_row_tiles = (a.rows + 16 * a.mi - 1) / (16 * a.mi);
-    }
-    dim3 grid(prune_gemm_blocks(n_categories, a.n_col_tiles, a.n_row_tiles, n_cu), 1, 1);
+hipError_t launch_prune_gemm(const GemmArgs& a, GemmVariant v, int blocks, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    if (!a.ops || a.n_ops < 1 || a.n_ops > kMaxGroupOps || !a.plan || a.plan_rounds < 1 || blocks < 8 || (blocks & 7)) return hipErrorInvalidValue;
+    if (v.leaf == 2 && (v.mode || v.trans)) return hipErrorInvalidValue;       // the schedule never asks for these
+    if (v.trans && (v.leaf || v.mode)) return hipErrorInvalidValue;
+    dim3 grid(blocks, 1, 1);
     (void)hipGetLastError();
     switch (a.mi) {
-        case 4: launch_mi<4>(a, grid, stream, ev0, ev1); break;
-        case 5: launch_mi<5>(a, grid, stream, ev0, ev1); break;
-        case 6: launch_mi<6>(a, grid, stream, ev0, ev1); break;
-        case 7: launch_mi<7>(a, grid, stream, ev0, ev1); break;
-        case 8: launch_mi<8>(a, grid, stream, ev0, ev1); break;
-        case 9: launch_mi<9>(a, grid, stream, ev0, ev1); break;
+        case 4: launch_mi<4>(a, v, grid, stream, ev0, ev1); break;
+        case 5: launch_mi<5>(a, v, grid, stream, ev0, ev1); break;
+        case 6: launch_mi<6>(a, v, grid, stream, ev0, ev1); break;
+        case 7: launch_mi<7>(a, v, grid, stream, ev0, ev1); break;
+        case 8: launch_mi<8>(a, v, grid, stream, ev0, ev1); break;
+        case 9: launch_mi<9>(a, v, grid, stream, ev0, ev1); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

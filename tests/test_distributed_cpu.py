@@ -59,6 +59,18 @@ def test_shard_plan_is_a_balanced_partition(world):
         assert cost.sum() < sum(_distinct_columns(pb, b) for b in blocks)
 
 
+def test_shard_plan_of_identical_families_is_even():
+    """64 copies of one family: all columns are shared, what is left is the per-family term -- the shards must come out
+    about equal (a start vector that counted first-seen patterns only gave [1, 1, 17, 45])."""
+    sys.path.insert(0, ROOT)
+    import dataclasses
+    from cafexp_amd import capi, synth
+    pb, _ = synth.make_problem(n_taxa=12, n_families=64, max_count=60, lam_sim=0.004, seed=3, root_cap=40)
+    same = dataclasses.replace(pb, counts=np.repeat(pb.counts[:1], 64, axis=0).copy())
+    sizes = [len(x) for x in capi.shard_plan(same, 4)]
+    assert sum(sizes) == 64 and min(sizes) >= 10 and max(sizes) <= 22, sizes
+
+
 def test_shard_plan_rejects_more_shards_than_families():
     sys.path.insert(0, ROOT)
     from cafexp_amd import capi, synth

@@ -291,18 +291,27 @@ def test_subtree_dedup_is_bit_identical(capi, oracle, golden, name):
 
 
 def test_chunked_workspace_equals_single_chunk(capi, oracle):
+    """A workspace limit makes the library prune the families in column chunks (one column per family, one op per launch, the
+    Sethi-Ullman slot pool).  600 families = 5 column tiles: two or three chunks end with a NARROWER last chunk, which gets
+    tile lists of its own."""
     rng = np.random.default_rng(11)
-    pb = _random_problem(rng, "(((A:1,B:1):1,(C:1,D:1):1):1,((E:1,F:1):1,(G:1,H:1):1):1);", 700, 60, 50, 25)
+    pb = _random_problem(rng, "(((A:1,B:1):1,(C:1,D:1):1):1,((E:1,F:1):1,(G:1,H:1):1):1);", 600, 60, 50, 25)
     probs, mult = oracle.discrete_gamma(2, 2.0)
     pr = P.Params(lambdas=np.array([0.01]), prior=P.prior_uniform(50), multipliers=mult, cat_probs=probs)
     one = capi.Context(pb, max_categories=2)
-    many = capi.Context(pb, max_categories=2, workspace_limit=6 * 2 * 80 * 8 * 256 + 1)   # room for 256 columns (6 panels x 2 categories x 80 rows) -> 3 chunks
     v1, r1 = one.score(pr, alpha=2.0, per_family=True)
-    v2, r2 = many.score(pr, alpha=2.0, per_family=True)
-    assert many.stats()["n_chunks"] >= 3 and one.stats()["n_chunks"] == 1
-    assert np.array_equal(r1["family_likelihood"], r2["family_likelihood"])
-    assert rel_err(v1, v2) <= 1e-14
+    assert one.stats()["n_chunks"] == 1
     assert rel_err(v1, oracle.score_gamma(pb, pr)) <= SCORE_TOL
+    seen = set()
+    for tiles in (1, 2, 3, 4):                                   # (room for `tiles` column tiles if the pool has 5 panels of 80 rows x 2 categories)
+        many = capi.Context(pb, max_categories=2, workspace_limit=5 * 2 * 80 * 8 * 128 * tiles + 1)
+        for _ in range(2):
+            v2, r2 = many.score(pr, alpha=2.0, per_family=True)
+            assert np.array_equal(r1["family_likelihood"], r2["family_likelihood"])
+            assert rel_err(v1, v2) <= 1e-14
+        seen.add(many.stats()["n_chunks"])
+        many.close()
+    assert max(seen) >= 3 and seen & {2, 3}, seen            # (2 or 3 chunks of 5 column tiles: the last one is narrower)
 
 
 def test_repeated_calls_are_stateless(capi, oracle):
@@ -671,10 +680,10 @@ def test_assemble_pass_skips_rows_outside_the_extent_without_changing_a_bit(capi
 
 @pytest.mark.gpu
 def test_planned_tile_lists_cover_every_tile_once_and_change_no_bit(capi, oracle, monkeypatch):
-    """With K loops of unequal length the tiles of a K2 launch are dealt to the workgroups by a planner kernel (extents.hip,
-    tile_plan_kernel: per round, longest tile to least-loaded workgroup) instead of in fixed strides.  The lists read back from
-    the device hold every tile of every launch exactly once, with the K range the extents give; results have the bits of a
-    context without the planner (CAFE_NO_PLAN), call after call as the extents change."""
+    """The tiles of a K2 launch -- the tiles of every op of its group -- are dealt to the workgroups by a planner kernel
+    (extents.hip, tile_plan_kernel: per round, longest tile to least-loaded workgroup).  The lists read back from the device
+    hold every tile of every op of every launch exactly once, with the K range the extents give; results have the bits of a
+    context that launches one op at a time (CAFE_NO_GROUPS), call after call as the extents change."""
     pb, _ = synth.make_problem(n_taxa=16, n_families=1500, max_count=250, lam_sim=0.003, seed=11, root_cap=120)
     assert pb.matrix_size >= 256
     probs, mult = oracle.discrete_gamma(3, 0.9)
@@ -689,11 +698,11 @@ def test_planned_tile_lists_cover_every_tile_once_and_change_no_bit(capi, oracle
         assert 1.0 <= worst < 3.0
     v, r = ctx.score(prs[0], per_family=True)                # base model: one category, other lists
     assert ctx.plan_check()[0] == ctx.stats()["gemm_launches"]
-    monkeypatch.setenv("CAFE_NO_PLAN", "1")
+    monkeypatch.setenv("CAFE_NO_GROUPS", "1")
     plain = capi.Context(pb, max_categories=3)
     for pr, (v1, r1) in zip(prs, got):
         v2, r2 = plain.score(pr, alpha=0.9, per_family=True)
-        assert plain.plan_check()[0] == 0
+        assert plain.plan_check()[0] == plain.stats()["gemm_launches"] > ctx.stats()["gemm_launches"]
         assert v1 == v2
         for key in r1:
             assert np.array_equal(r1[key], r2[key]), key
@@ -713,12 +722,13 @@ def test_random_shapes_with_and_without_the_work_skipping_have_the_same_bits():
 
 
 @pytest.mark.gpu
-def test_second_stream_for_the_roots_other_subtree_changes_no_bit(capi, oracle, monkeypatch):
-    """CAFE_STREAMS=2 (experimental, read at cafe_create): the root's second interior subtree gets panels of its own and
-    runs on a second stream, forked behind K1 / extents / planner and joined in front of the root's launches.  Same bits
-    as the one-stream schedule, call after call, base and gamma, with and without an error model."""
-    for n_dev in (0, 3):
-        pb, _ = synth.make_problem(n_taxa=24, n_families=1200, max_count=260, lam_sim=0.003, seed=23, root_cap=120, n_deviations=n_dev)
+def test_grouped_launches_equal_the_one_op_per_launch_schedule(capi, oracle, monkeypatch):
+    """The default schedule levels the ops by their dependencies and sends the ops of a step that share a kernel variant out
+    in ONE launch (every panel has a place of its own in the arena); CAFE_NO_GROUPS keeps the post-order schedule with one
+    op per launch and the Sethi-Ullman slot pool.  Same bits, call after call, base and gamma, with and without an error
+    model and subtree sharing, small matrices (no extents) and large ones -- with fewer launches."""
+    for n_dev, max_count, n_taxa in ((0, 260, 24), (3, 260, 24), (0, 60, 13)):
+        pb, _ = synth.make_problem(n_taxa=n_taxa, n_families=1200, max_count=max_count, lam_sim=0.003, seed=23, root_cap=max_count // 2, n_deviations=n_dev)
         em = None
         if n_dev:
             em = P.error_model_table(P.default_error_model(pb.max_family_size)[:1] + [[0.05, 0.9, 0.05]], pb.max_family_size)
@@ -726,19 +736,22 @@ def test_second_stream_for_the_roots_other_subtree_changes_no_bit(capi, oracle, 
         prs = [(P.Params(lambdas=np.array([l]), prior=P.prior_uniform(pb.max_root_family_size), multipliers=mult, cat_probs=probs, error_model=em), 0.8)
                for l in (0.004, 0.0007)]
         prs.append((P.Params(lambdas=np.array([0.002]), prior=P.prior_uniform(pb.max_root_family_size), error_model=em), 1.0))
-        monkeypatch.setenv("CAFE_STREAMS", "1")
-        one = capi.Context(pb, max_categories=4)
-        monkeypatch.setenv("CAFE_STREAMS", "2")
-        two = capi.Context(pb, max_categories=4)
-        monkeypatch.delenv("CAFE_STREAMS")
-        assert two.stats()["panel_bytes"] > one.stats()["panel_bytes"]          # (the side subtree's own panels)
-        for _ in range(2):
-            for pr, alpha in prs:
-                v1, r1 = one.score(pr, alpha=alpha, per_family=True)
-                v2, r2 = two.score(pr, alpha=alpha, per_family=True)
-                assert v1 == v2
-                for key in r1:
-                    assert np.array_equal(r1[key], r2[key]), key
+        for subtree_dedup in (True, False):
+            grouped = capi.Context(pb, max_categories=4, subtree_dedup=subtree_dedup)
+            monkeypatch.setenv("CAFE_NO_GROUPS", "1")
+            single = capi.Context(pb, max_categories=4, subtree_dedup=subtree_dedup)
+            monkeypatch.delenv("CAFE_NO_GROUPS")
+            for _ in range(2):
+                for pr, alpha in prs:
+                    v1, r1 = single.score(pr, alpha=alpha, per_family=True)
+                    v2, r2 = grouped.score(pr, alpha=alpha, per_family=True)
+                    assert v1 == v2
+                    for key in r1:
+                        assert np.array_equal(r1[key], r2[key]), key
+            assert grouped.stats()["gemm_launches"] < single.stats()["gemm_launches"]
+            want = oracle.score(pb, prs[2][0])
+            assert rel_err(grouped.score(prs[2][0]), want) <= SCORE_TOL
+            grouped.close(); single.close()
 
 
 @pytest.mark.gpu

@@ -5,7 +5,11 @@ N = 751; user_data.cpp:45-46, base_model.cpp:77).  tests/golden/ref_n751.json wa
     incl. the smallest and the largest multiplier of K = 8 at alpha = 2          (matrix_cache.cpp:121-171)
   * a gamma K = 8 score, per family and category, on a 12-taxon tree whose table holds a 600   (gamma_core.cpp:169-244)
   * a base-model score with a lambda tree (two rates) and a 3-tap error model whose last row differs from the others and
-    has a family sitting on it (config 5's shape; probability.cpp:182-193, error_model.cpp:52-57), and the plain base score.
+    has a family sitting on it (config 5's shape; probability.cpp:182-193, error_model.cpp:52-57), and the plain base score
+  * the bench's OWN 100-taxon tree (config 4's shape exactly: 198 branches x 8 categories of order-751 matrices, half an hour
+    of reference time per score) with four families of the bench tables: per family and category at the bench's scoring
+    point, and a point where the reference rejects the call because one family's slowest category has an all-zero root
+    vector (gamma_core.cpp:152, :227) -- found on the GPU over all 50 000 families (profiles/r03_zero_categories.json).
 CPU tests pin the oracle to them; the -m gpu tests compare the HIP path with the same reference outputs."""
 import json
 import math
@@ -19,7 +23,8 @@ from helpers import case_from_args, rel_err
 TIGHT = 1e-12          # oracle (same algorithm as the reference) against the reference
 SCORE_TOL = 1e-10      # HIP path: -lnL and per-family values
 VEC_TOL = 5e-11        # HIP path: matrix entries (O(N^2) recurrence against the reference's O(N^3) log-space sums)
-SCORES = ["big12_gamma_k8", "big12_multilambda_err", "big12_base"]
+SCORES = ["big12_gamma_k8", "big12_multilambda_err", "big12_base", "bench100_gamma_k8_l0.002_a2"]
+INF = "bench100_gamma_k8_l0.002_a1.5_inf"
 
 
 @pytest.fixture(scope="module")
@@ -48,6 +53,17 @@ def test_fixture_is_at_the_bench_matrix_order(n751):
         assert (e["max_family_size"], e["max_root_family_size"]) == (720, 750) and math.isfinite(e["neg_lnl"])
     lams = sorted(m["lambda"] for m in n751["matrices"])
     assert lams[0] < 0.0005 and lams[-1] > 0.004     # the smallest and the largest multiplier of K = 8 at lambda 0.002, alpha 2
+
+
+def test_oracle_rejects_where_the_reference_does_at_100_taxa(oracle, n751):
+    e = n751["scores"][INF]
+    assert e["neg_lnl"] == math.inf and (e["max_family_size"], e["max_root_family_size"]) == (720, 750)
+    pb, pr, alpha = case_from_args(e["args"], oracle)
+    assert pb.n_taxa == 100 and pb.n_families == 4
+    v, cat, fam = oracle.score_gamma(pb, pr, fast=True, per_family=True)
+    assert v == math.inf
+    # the slowest category of the large family from the SURVEY-8d table (the restatement, like gamma_model::prune, stops there)
+    assert cat[3, 0] == 0 and (cat[:3] > 0).all()
 
 
 @pytest.mark.parametrize("i", [0, 1, 2])
@@ -121,3 +137,17 @@ def test_gpu_scores_at_751_against_the_reference(capi, oracle, n751, name):
         else:
             assert np.abs(res["family_lnl"] / np.array(e["family_lnl"]) - 1).max() <= SCORE_TOL
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_rejects_where_the_reference_does_at_100_taxa(capi, oracle, n751):
+    """The same four families on the bench's 100-taxon tree: +inf at lambda 0.002 / alpha 1.5 like the reference (one
+    category of one family is exactly zero -- and only that one), finite at alpha 2 (the SCORES case above)."""
+    e = n751["scores"][INF]
+    pb, pr, alpha = case_from_args(e["args"], oracle)
+    ctx = capi.Context(pb, max_categories=8)
+    assert ctx.score(pr, alpha=alpha) == math.inf
+    # a zero-sum category is a numeric rejection, not an error: the per-family values are there (gamma_core.cpp:227-236)
+    res = ctx.family_results(8)
+    assert list(res["failed"]) == [0, 0, 0, 1] and res["category_likelihood"][3, 0] == 0 and (res["category_likelihood"][:3] > 0).all()
+    ctx.close()

@@ -1,5 +1,5 @@
 """Randomised cross-check of everything that decides WHICH work K2 / the assemble pass do (zero extents, planned tile lists,
-rows left out by the assemble pass, tile heights): random trees, tables, rates, categories, error models, several calls per
+rows left out by the assemble pass, tile heights, grouped launches): random trees, tables, rates, categories, error models, several calls per
 context; every per-family value must have the bits of a context created with all of it switched off (CAFE_NO_KSKIP).
 Usage: fuzz_extents.py [cases] [seed]"""
 import os, sys
@@ -40,8 +40,11 @@ for case in range(n_cases):
     fast = capi.Context(pb, max_categories=8)
     os.environ.pop("CAFE_FORCE_TILE", None)
     os.environ["CAFE_NO_KSKIP"] = "1"
+    if rng.integers(0, 2) == 0:
+        os.environ["CAFE_NO_GROUPS"] = "1"                   # ... and one op per launch from the slot pool (the grouped schedule is the default)
     plain = capi.Context(pb, max_categories=8)
     os.environ.pop("CAFE_NO_KSKIP")
+    os.environ.pop("CAFE_NO_GROUPS", None)
     ok = True
     for pr, alpha in calls + calls[:1]:
         def run(ctx):
