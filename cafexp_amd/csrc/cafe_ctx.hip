@@ -1180,7 +1180,8 @@ int record_call(cafe_ctx* c, DescSet& ds, int K, bool gamma, bool rootmax, bool 
             planned_cols = cols;
             ds.plan_static_valid = false;
         }
-        if (plan_needed && c->n_gemm_groups > 0) HIP_TRY(c, launch_tile_plan(ds.d_plan_desc, c->n_gemm_groups, s));
+        if (plan_needed && c->n_gemm_groups > 0)
+            HIP_TRY(c, launch_tile_plan(ds.d_plan_desc, c->n_gemm_groups, *std::max_element(ds.group_rounds.begin(), ds.group_rounds.end()), s));
         plan_needed = false;
         int gi = 0;
         for (size_t g_index = 0; g_index < c->groups.size(); ++g_index) {

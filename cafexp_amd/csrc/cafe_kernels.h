@@ -129,7 +129,8 @@ struct PlanLaunch {
     int2* plan;                     // [8][blocks_per_xcd][rounds]
 };
 constexpr int kPlanSlack = 2;       // spare list entries per workgroup (the planner's last rounds are dealt as one batch)
-hipError_t launch_tile_plan(const PlanLaunch* d_launches, int n_launches, hipStream_t stream);
+// max_rounds: the longest PlanLaunch::rounds of the launches (the planner's grid depth)
+hipError_t launch_tile_plan(const PlanLaunch* d_launches, int n_launches, int max_rounds, hipStream_t stream);
 // workgroups of a K2 launch (a multiple of 8) whose busiest XCD owns `tiles_xcd0` tiles: two per CU, fewer when there are fewer tiles
 int prune_gemm_blocks(int64_t tiles_xcd0, int n_cu);
 // tiles XCD 0 owns of an op with n_pairs = categories * column tiles

@@ -10,6 +10,8 @@
 // runs, for a (row tile, column tile) pair, only the K tiles inside the intersection of the matrix extent and the panel
 // extent: every product it leaves out has an exact zero in it, so no bit of any result changes (the reference has no
 // counterpart: it multiplies all (M+1)^2 entries for every family, matrix_cache.cpp:28-57).
+#include <algorithm>
+
 #include "cafe_kernels.h"
 
 namespace cafe {
@@ -113,6 +115,10 @@ __device__ inline int2 plan_tile_entry(const PlanLaunch& L, const int* s_first, 
 
 // The last kPlanTail rounds are dealt as ONE batch, longest tile first, each to the workgroup with the least load at that
 // moment (a workgroup may then end up with a tile more or less than its neighbours: lists have kPlanSlack spare entries).
+// The rounds before them are dealt in chunks of kPlanChunk rounds, one wave per chunk (blockIdx.z), each balancing its own
+// rounds from a load of zero -- a launch of a whole tree level has hundreds of rounds, and one wave dealing them one after
+// the other took 1.8 ms in front of the first K2 launch of a config-4 call.
+constexpr int kPlanChunk = 32;
 __global__ __launch_bounds__(64) void tile_plan_kernel(const PlanLaunch* __restrict__ launches) {
     const PlanLaunch& L = launches[blockIdx.y];
     const int xcd = blockIdx.x, lane = threadIdx.x;
@@ -135,8 +141,10 @@ __global__ __launch_bounds__(64) void tile_plan_kernel(const PlanLaunch* __restr
     s_load[lane] = 0;
     __syncthreads();
     const int head = max(0, (n_tiles + nlb - 1) / nlb - kPlanTail);      // full rounds dealt one by one
+    const int n_chunks = max(1, (head + kPlanChunk - 1) / kPlanChunk), chunk = blockIdx.z;
+    if (chunk >= n_chunks) return;                          // (block-uniform: the grid is as deep as the launch with most rounds)
     int2* __restrict__ mylist = L.plan + ((int64_t)xcd * nlb + lane) * L.rounds;   // (lanes < nlb)
-    for (int r = 0; r < head; ++r) {
+    for (int r = chunk * kPlanChunk; r < min(head, (chunk + 1) * kPlanChunk); ++r) {
         const int t = r * nlb + lane;
         const bool valid = lane < nlb;
         int2 en = make_int2(0, 0);
@@ -161,7 +169,8 @@ __global__ __launch_bounds__(64) void tile_plan_kernel(const PlanLaunch* __restr
         }
         __syncthreads();
     }
-    // ---- the rest as one batch
+    if (chunk != n_chunks - 1) return;
+    // ---- the rest as one batch, by the wave that dealt the last chunk (on top of that chunk's loads)
     const int t0 = head * nlb, n_tail = n_tiles - t0;
     for (int i = lane; i < n_tail; i += 64) {
         const int2 en = plan_tile_entry(L, s_first, xcd, t0 + i);
@@ -192,10 +201,11 @@ __global__ __launch_bounds__(64) void tile_plan_kernel(const PlanLaunch* __restr
         for (; pos < L.rounds; ++pos) mylist[pos] = make_int2(0, 0);
 }
 
-hipError_t launch_tile_plan(const PlanLaunch* d_launches, int n_launches, hipStream_t stream) {
+hipError_t launch_tile_plan(const PlanLaunch* d_launches, int n_launches, int max_rounds, hipStream_t stream) {
     if (n_launches <= 0) return hipSuccess;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(tile_plan_kernel, dim3(8, n_launches), dim3(64), 0, stream, d_launches);
+    const int chunks = std::max(1, (std::max(0, max_rounds - kPlanSlack - kPlanTail) + kPlanChunk - 1) / kPlanChunk);
+    hipLaunchKernelGGL(tile_plan_kernel, dim3(8, n_launches, chunks), dim3(64), 0, stream, d_launches);
     return hipGetLastError();
 }
 

@@ -63,9 +63,12 @@ __device__ inline double vmax(double a, double b) {
 // waves of a block share the family columns (L1 hits) and split 64 parent sizes.  Steps run in groups of four
 // with the next group's panel values already in flight; rows M+1.. of the group padding multiply zero matrix rows
 // (the k-major matrix is zero beyond row M, the panel workspace beyond row M is zeroed once).
+// ext (or nullptr): K1's non-zero extents of this matrix -- per block of 16 parent sizes the first / last child size j with a
+// non-zero entry.  A wave's 16 parent sizes are exactly one such block, so its j loop runs over that range only: every
+// product left out is b * 0 = 0, and max(acc, 0) = acc (acc starts at 0, all terms are >= 0): the same bits.
 template <bool MUL>
 __global__ __launch_bounds__(256) void maxprod_kernel(const double* __restrict__ Pt, int ldp, const double* __restrict__ B,
-                                                      double* __restrict__ dst, int64_t ld, int M, int kc_rows) {
+                                                      double* __restrict__ dst, int64_t ld, int M, int kc_rows, const int32_t* __restrict__ ext) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // XCD-aware order: workgroups b, b+8, ... share an XCD; consecutive ones there take the row groups of ONE
@@ -82,14 +85,23 @@ __global__ __launch_bounds__(256) void maxprod_kernel(const double* __restrict__
     for (int t = 0; t < kTI; ++t) acc[t] = 0.0;                  // all products are >= 0: same result as the reference's -1 start
     const double* bp = B + f;
     const double* pp = Pt + i0;
-    const int groups = (M + 4) / 4;                              // rows 0 .. 4*groups-1 cover 0..M
+    int groups = (M + 4) / 4;                                    // rows 0 .. 4*groups-1 cover 0..M
+    int g0 = 0;
+    if (ext) {
+        const int lo = ext[2 * (i0 / kTI)], hi = ext[2 * (i0 / kTI) + 1];
+        if (hi < lo) { g0 = 0; groups = 0; }                     // an all-zero block of the matrix: acc stays 0
+        else { g0 = __builtin_amdgcn_readfirstlane(lo / 4); groups = __builtin_amdgcn_readfirstlane(min(groups, hi / 4 + 1)); }
+    }
     double bn[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) bn[u] = bp[(int64_t)u * ld];
+    for (int u = 0; u < 4; ++u) bn[u] = bp[(int64_t)(4 * g0 + u) * ld];
     double pn[kTI];                                              // the matrix row of the NEXT step, already requested
+    {
+        const double* prow0 = pp + (int64_t)min(4 * g0, kc_rows - 1) * ldp;
 #pragma unroll
-    for (int t = 0; t < kTI; ++t) pn[t] = pp[t];
-    for (int g = 0; g < groups; ++g) {
+        for (int t = 0; t < kTI; ++t) pn[t] = prow0[t];
+    }
+    for (int g = g0; g < groups; ++g) {
         double b[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) b[u] = bn[u];
@@ -285,8 +297,9 @@ int reconstruct_impl(cafe_ctx* c, const cafe_params* pr, const float* root_prior
                     const double* B = d_B + (int64_t)bidx[v] * pstride;
                     const int n_ct = (int)(ld / 64), n_rg = (M + kRowsPerBlock - 1) / kRowsPerBlock;
                     dim3 grid((unsigned)(8 * ((n_ct + 7) / 8) * n_rg));
-                    if (mul) hipLaunchKernelGGL(maxprod_kernel<true>, grid, dim3(256), 0, s, Pt, c->kpool.ld, B, dst, ld, M, c->kpool.rows);
-                    else hipLaunchKernelGGL(maxprod_kernel<false>, grid, dim3(256), 0, s, Pt, c->kpool.ld, B, dst, ld, M, c->kpool.rows);
+                    const int32_t* ext = c->kpool.ext ? c->kpool.ext + (size_t)slot * c->kpool.ext_blocks * 2 : nullptr;
+                    if (mul) hipLaunchKernelGGL(maxprod_kernel<true>, grid, dim3(256), 0, s, Pt, c->kpool.ld, B, dst, ld, M, c->kpool.rows, ext);
+                    else hipLaunchKernelGGL(maxprod_kernel<false>, grid, dim3(256), 0, s, Pt, c->kpool.ld, B, dst, ld, M, c->kpool.rows, ext);
                 }
                 HIP_TRY(c, hipGetLastError());
             }
