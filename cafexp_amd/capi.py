@@ -70,7 +70,7 @@ EXPORTS = [
     "cafe_comm_unique_id", "cafe_comm_attach", "cafe_comm_detach", "cafe_shard_plan", "cafe_shard_plan_scaled", "cafe_create_sharded",
     "cafe_sharded_destroy", "cafe_sharded_last_error", "cafe_sharded_score", "cafe_sharded_family_results",
     "cafe_sharded_size", "cafe_sharded_context", "cafe_set_graphs", "cafe_executed_flops", "cafe_get_extents", "cafe_debug_launch_flops", "cafe_debug_launch_ms", "cafe_debug_plan_check",
-    "cafe_debug_fail_next",
+    "cafe_debug_fail_next", "cafe_debug_column_extents",
 ]
 CAFE_COMM_ID_BYTES = 128
 
@@ -427,6 +427,15 @@ class Context:
         self._check(self._lib.cafe_get_extents(self._h, node, category, _p(m, _i32p), m.size, _p(pt, _i32p), pt.size, C.byref(nt)))
         leaf = self.problem.leaf_taxon[node] >= 0
         return (m[:n] if leaf else m[:(n - 1 + 15) // 16]), (pt[:nt.value] if nt.value else None)
+
+    def column_extents(self, node: int, category: int = 0) -> np.ndarray:
+        """Per-column zero extents [columns][2] of an interior non-root node's panel in the last call (diagnostic)."""
+        self._lib.cafe_debug_column_extents.restype = C.c_int
+        self._lib.cafe_debug_column_extents.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _i32p, C.c_size_t, C.POINTER(C.c_int64)]
+        out = np.zeros((self.n_families + 256, 2), dtype=np.int32)
+        n = C.c_int64()
+        self._check(self._lib.cafe_debug_column_extents(self._h, node, category, _p(out, _i32p), out.size, C.byref(n)))
+        return out[:n.value]
 
     def launch_flops(self):
         """Per K2 launch of the last call: (executed flops, flops over all K tiles, tile height in 16-row blocks)."""

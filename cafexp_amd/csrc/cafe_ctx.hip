@@ -1702,6 +1702,22 @@ int cafe_get_extents(cafe_ctx* ctx, int32_t node, int32_t category, int32_t* mat
     return CAFE_OK;
 }
 
+int cafe_debug_column_extents(cafe_ctx* ctx, int32_t node, int32_t category, int32_t* out, size_t out_len, int64_t* n_cols) {
+    if (!ctx || !out) return CAFE_ERR_ARGUMENT;
+    if (!ctx->have_results || ctx->last_rejected) { set_err(ctx, "cafe_debug_column_extents: no completed call"); return CAFE_ERR_STATE; }
+    if (node < 0 || node >= ctx->n_nodes || category < 0 || category >= ctx->K_last || !ctx->panel_extents || !ctx->d_colext[node]) {
+        set_err(ctx, "cafe_debug_column_extents: no extents for this node");
+        return CAFE_ERR_ARGUMENT;
+    }
+    const int64_t cols = ctx->subtree_dedup ? ctx->pat_cols[node] : ctx->Fp;
+    if (n_cols) *n_cols = cols;
+    if (out_len < (size_t)2 * cols) { set_err(ctx, "cafe_debug_column_extents: out too small"); return CAFE_ERR_ARGUMENT; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->d_colext[node] + (size_t)category * cols * 2, sizeof(int32_t) * 2 * cols, hipMemcpyDeviceToHost));
+    return CAFE_OK;
+}
+
 int cafe_executed_flops(cafe_ctx* ctx, double* flops) {
     if (!ctx || !flops) return CAFE_ERR_ARGUMENT;
     if (!ctx->have_results) { set_err(ctx, "cafe_executed_flops: no completed call"); return CAFE_ERR_STATE; }

@@ -248,6 +248,9 @@ int cafe_get_root_likelihoods(cafe_ctx* ctx, int64_t family, int32_t category, d
  *               may be non-zero, [columns / 128][2]; *n_tiles receives the number of tiles. */
 int cafe_get_extents(cafe_ctx* ctx, int32_t node, int32_t category, int32_t* matrix_ext, size_t matrix_ext_len,
                      int32_t* panel_ext, size_t panel_ext_len, int32_t* n_tiles);
+/* diagnostic: the per-COLUMN zero extents of an interior non-root node's panel in the last call, out[columns][2] (rows outside
+ * [lo, hi] of a column are exactly zero; lo > hi: the whole column); *n_cols receives the panel's (padded) column count */
+int cafe_debug_column_extents(cafe_ctx* ctx, int32_t node, int32_t category, int32_t* out, size_t out_len, int64_t* n_cols);
 int cafe_get_stats(const cafe_ctx* ctx, cafe_stats* stats);
 /* Flops the K2 launches of the last call executed: a (row tile, column tile) pair runs only the K tiles inside the
  * intersection of the matrix's non-zero extent (K1) and the panel's (extents.hip) -- the products it leaves out all have an

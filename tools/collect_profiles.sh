@@ -29,6 +29,12 @@ cd $R
 tail -1 $OUT/bench_full.json | cut -c1-300
 echo "[7/8] eight shards, one after the other (what each rank of an 8-GPU run does)"
 bash tools/shard_rehearsal.sh 8 | tail -4
-echo "[8/8] the launcher path: python bench.py --gpus 2 (gloo rehearsal, both ranks on this GPU)"
+echo "[8/8] the launcher path: python bench.py --gpus 2 (gloo rehearsal, both ranks on this GPU) + per-launch table + shard kernel trace"
 timeout -k 10 300 python3 bench.py --gpus 2 --backend gloo --steps 3 --no-cpu-baseline > $OUT/bench_gloo2.json 2> $OUT/bench_gloo2.err
 cut -c1-200 $OUT/bench_gloo2.json
+timeout -k 10 200 python3 tools/launch_table.py > $OUT/launch_table_full.txt 2>/dev/null
+timeout -k 10 200 python3 tools/launch_table.py 3/8 > $OUT/launch_table_shard3.txt 2>/dev/null
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_shard -o run --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --emulate-shard 3/8 > $OUT/prof_shard.log 2>&1
+find $OUT/prof_shard -name "*kernel_trace.csv" -delete
+cd $R
