@@ -881,7 +881,7 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
                     const int64_t gc = c->subtree_dedup ? c->pat_cols[op.child] : c->chunk_cols;
                     tiles += prune_gemm_tiles_xcd0(c->Kmax, (int)(gc / kBN), (rows + 16 * mi - 1) / (16 * mi));
                 }
-                worst = std::max(worst, (size_t)8 * (size_t)(tiles + 64 * (1 + kPlanSlack)));   // >= 8 * nlb * (ceil(tiles / nlb) + slack), any K <= Kmax
+                worst = std::max(worst, (size_t)8 * (size_t)(tiles + kPlanLanes * (1 + kPlanSlack)));   // >= 8 * nlb * (ceil(tiles / nlb) + slack), any K <= Kmax
             }
             entries += worst;
         }
@@ -1000,13 +1000,14 @@ bool rejected(const cafe_ctx* c, const cafe_params* pr, int K) {
 // block; the efficiency factors are measured (forced tile heights): even heights stage a padded A tile.
 int pick_tile_height(const cafe_ctx* c, const int32_t* ext, const Group& g, int K, int64_t chunk_cols) {
     static const double eff[10] = {0, 0, 0, 0, 1.12, 1.03, 1.30, 1.06, 1.05, 1.00};
-    const int nb = c->kpool.ext_blocks, slots = 2 * c->n_cu / 8 * 8;
+    const int nb = c->kpool.ext_blocks;
     const int n_k = (c->M + 1 + kBK - 1) / kBK;
     const double overhead = 2.0;             // prologue + epilogue of a tile, in K tiles
     int best = 9;
     double best_cost = 1e300;
     for (int mi = 9; mi >= 4; --mi) {
         if (mi == 6) continue;
+        const int slots = prune_gemm_wg_per_cu(mi) * c->n_cu / 8 * 8;
         double work = 0, tiles = 0;          // sum over (op, category, row tile, column tile) of (K tiles + overhead) * height; tiles
         for (int oi : g.ops) {
             const Op& op = c->ops[oi];
@@ -1048,7 +1049,6 @@ int prepare_descriptors(cafe_ctx* c, DescSet& ds, int K, int64_t cols, const std
     ds.group_plan_off.assign(c->n_gemm_groups, 0);
     std::vector<GemmOp> ops = c->h_gemm_ops;
     std::vector<PlanLaunch> plans(c->n_gemm_groups);
-    const int slots = 2 * c->n_cu / 8 * 8;
     size_t used = 0;
     int gi = 0;
     for (const Group& g : c->groups) {
@@ -1063,7 +1063,7 @@ int prepare_descriptors(cafe_ctx* c, DescSet& ds, int K, int64_t cols, const std
                     const int64_t gc = c->subtree_dedup ? c->pat_cols[op.child] : cols;
                     tiles_by_mi[h] += (int64_t)(((op.to_root ? c->R : c->M) + 16 * h - 1) / (16 * h)) * (gc / kBN) * K;
                 }
-            mi = prune_gemm_pick_mi(tiles_by_mi, slots);
+            mi = prune_gemm_pick_mi(tiles_by_mi, c->n_cu);
         }
         int64_t tiles0 = 0;
         for (int oi : g.ops) {
@@ -1073,7 +1073,7 @@ int prepare_descriptors(cafe_ctx* c, DescSet& ds, int K, int64_t cols, const std
             const int64_t gc = c->subtree_dedup ? c->pat_cols[op.child] : cols;
             tiles0 += prune_gemm_tiles_xcd0(K, (int)(gc / kBN), d.n_row_tiles);
         }
-        const int blocks = prune_gemm_blocks(tiles0, c->n_cu), nlb = blocks / 8;
+        const int blocks = prune_gemm_blocks(tiles0, c->n_cu, mi), nlb = blocks / 8;
         const int rounds = (int)((tiles0 + nlb - 1) / nlb) + kPlanSlack;
         const size_t need = (size_t)8 * nlb * rounds;
         if (used + need > c->plan_entries) { set_err(c, "internal: tile lists do not fit (%zu + %zu > %zu)", used, need, c->plan_entries); return CAFE_ERR_STATE; }

@@ -131,8 +131,12 @@ struct PlanLaunch {
 constexpr int kPlanSlack = 2;       // spare list entries per workgroup (the planner's last rounds are dealt as one batch)
 // max_rounds: the longest PlanLaunch::rounds of the launches (the planner's grid depth)
 hipError_t launch_tile_plan(const PlanLaunch* d_launches, int n_launches, int max_rounds, hipStream_t stream);
-// workgroups of a K2 launch (a multiple of 8) whose busiest XCD owns `tiles_xcd0` tiles: two per CU, fewer when there are fewer tiles
-int prune_gemm_blocks(int64_t tiles_xcd0, int n_cu);
+// Workgroups of K2 resident on a CU: three for row tiles of up to 80 rows (52 KB of LDS each with an unpadded B tile, <= 168
+// vector registers), two for the taller ones (up to 72 KB, <= 250 registers).
+constexpr int prune_gemm_wg_per_cu(int mi) { return mi <= 5 ? 3 : 2; }
+constexpr int kPlanLanes = 128;     // workgroups of an XCD the tile planner can deal to (32 CUs x 3 = 96 on MI355X)
+// workgroups of a K2 launch (a multiple of 8) whose busiest XCD owns `tiles_xcd0` tiles: as many as are resident, fewer when there are fewer tiles
+int prune_gemm_blocks(int64_t tiles_xcd0, int n_cu, int mi);
 // tiles XCD 0 owns of an op with n_pairs = categories * column tiles
 inline int64_t prune_gemm_tiles_xcd0(int n_categories, int n_col_tiles, int n_row_tiles) {
     return (((int64_t)n_categories * n_col_tiles + 7) / 8) * n_row_tiles;
@@ -220,7 +224,7 @@ hipError_t launch_bd_matrix_build_both(const MatrixPool& pool, const MatrixPool&
 struct GemmVariant { int mode, leaf, trans; };
 hipError_t launch_prune_gemm(const GemmArgs& a, GemmVariant v, int blocks, hipStream_t stream, hipEvent_t ev_start = nullptr,
                              hipEvent_t ev_stop = nullptr);
-int prune_gemm_pick_mi(int64_t row_tile_pairs_by_mi[10], int slots);     // row-tile height (in 16-row blocks) from the group's tile counts per height
+int prune_gemm_pick_mi(int64_t row_tile_pairs_by_mi[10], int n_cu);     // row-tile height (in 16-row blocks) from the group's tile counts per height
 // what a K3 launch of a group of ops shares
 struct GatherGroup {
     MatrixPool pool;                // row-major pool

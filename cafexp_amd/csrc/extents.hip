@@ -119,9 +119,9 @@ __device__ inline int2 plan_tile_entry(const PlanLaunch& L, const int* s_first, 
 // rounds from a load of zero -- a launch of a whole tree level has hundreds of rounds, and one wave dealing them one after
 // the other took 1.8 ms in front of the first K2 launch of a config-4 call.
 constexpr int kPlanChunk = 32;
-__global__ __launch_bounds__(64) void tile_plan_kernel(const PlanLaunch* __restrict__ launches) {
+__global__ __launch_bounds__(kPlanLanes) void tile_plan_kernel(const PlanLaunch* __restrict__ launches) {
     const PlanLaunch& L = launches[blockIdx.y];
-    const int xcd = blockIdx.x, lane = threadIdx.x;
+    const int xcd = blockIdx.x, lane = threadIdx.x;         // lane = workgroup of the XCD (< blocks_per_xcd <= kPlanLanes)
     const int nlb = L.blocks_per_xcd;
     __shared__ int s_first[kMaxGroupOps + 1];
     if (lane == 0) {
@@ -135,9 +135,11 @@ __global__ __launch_bounds__(64) void tile_plan_kernel(const PlanLaunch* __restr
     }
     __syncthreads();
     const int n_tiles = s_first[L.n_ops];
+    // (two workgroups per CU, 64 per XCD: j and j + 32 share a CU and the first-dispatched one runs `bias` percent faster)
     const int weight = (nlb == 64 && L.bias) ? (lane < 32 ? 100 - L.bias : 100 + L.bias) : 100;   // of this lane's workgroup
-    __shared__ int s_load[64], s_cost[64], s_who[64];
-    __shared__ int t_cost[kPlanTail * 64], t_x[kPlanTail * 64], t_y[kPlanTail * 64], t_by_rank[kPlanTail * 64];
+    __shared__ int s_load[kPlanLanes], s_cost[kPlanLanes], s_who[kPlanLanes];
+    __shared__ unsigned s_key[kPlanLanes];
+    __shared__ int t_cost[kPlanTail * kPlanLanes], t_x[kPlanTail * kPlanLanes], t_y[kPlanTail * kPlanLanes], t_by_rank[kPlanTail * kPlanLanes];
     s_load[lane] = 0;
     __syncthreads();
     const int head = max(0, (n_tiles + nlb - 1) / nlb - kPlanTail);      // full rounds dealt one by one
@@ -170,16 +172,16 @@ __global__ __launch_bounds__(64) void tile_plan_kernel(const PlanLaunch* __restr
         __syncthreads();
     }
     if (chunk != n_chunks - 1) return;
-    // ---- the rest as one batch, by the wave that dealt the last chunk (on top of that chunk's loads)
+    // ---- the rest as one batch, by the block that dealt the last chunk (on top of that chunk's loads)
     const int t0 = head * nlb, n_tail = n_tiles - t0;
-    for (int i = lane; i < n_tail; i += 64) {
+    for (int i = lane; i < n_tail; i += kPlanLanes) {
         const int2 en = plan_tile_entry(L, s_first, xcd, t0 + i);
         t_cost[i] = (en.y & 0xFFFF) + L.fixed;
         t_x[i] = en.x;
         t_y[i] = en.y;
     }
     __syncthreads();
-    for (int i = lane; i < n_tail; i += 64) {
+    for (int i = lane; i < n_tail; i += kPlanLanes) {
         const int c = t_cost[i];
         int rank = 0;
         for (int j = 0; j < n_tail; ++j) rank += (t_cost[j] > c || (t_cost[j] == c && j < i)) ? 1 : 0;
@@ -188,11 +190,17 @@ __global__ __launch_bounds__(64) void tile_plan_kernel(const PlanLaunch* __restr
     __syncthreads();
     int pos = head;
     unsigned load = (unsigned)s_load[lane];
-    for (int q = 0; q < n_tail; ++q) {
+    for (int q = 0; q < n_tail; ++q) {                      // each item, longest first, to the workgroup with the least load now
         const int item = t_by_rank[q];
-        unsigned key = (lane < nlb && pos < L.rounds) ? ((min(load, 0x01FFFFFFu) << 6) | (unsigned)lane) : 0xFFFFFFFFu;
-        for (int off = 32; off > 0; off >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, off));
-        if (key != 0xFFFFFFFFu && lane == (int)(key & 63u)) {
+        s_key[lane] = (lane < nlb && pos < L.rounds) ? ((min(load, 0x00FFFFFFu) << 7) | (unsigned)lane) : 0xFFFFFFFFu;
+        __syncthreads();
+        for (int off = kPlanLanes / 2; off > 0; off >>= 1) {
+            if (lane < off) s_key[lane] = min(s_key[lane], s_key[lane + off]);
+            __syncthreads();
+        }
+        const unsigned key = s_key[0];
+        __syncthreads();
+        if (key != 0xFFFFFFFFu && lane == (int)(key & 127u)) {
             mylist[pos++] = make_int2(t_x[item], t_y[item]);
             load += (unsigned)(t_cost[item] * weight);
         }
@@ -205,7 +213,7 @@ hipError_t launch_tile_plan(const PlanLaunch* d_launches, int n_launches, int ma
     if (n_launches <= 0) return hipSuccess;
     (void)hipGetLastError();
     const int chunks = std::max(1, (std::max(0, max_rounds - kPlanSlack - kPlanTail) + kPlanChunk - 1) / kPlanChunk);
-    hipLaunchKernelGGL(tile_plan_kernel, dim3(8, n_launches, chunks), dim3(64), 0, stream, d_launches);
+    hipLaunchKernelGGL(tile_plan_kernel, dim3(8, n_launches, chunks), dim3(kPlanLanes), 0, stream, d_launches);
     return hipGetLastError();
 }
 

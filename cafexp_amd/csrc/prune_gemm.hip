@@ -47,7 +47,11 @@ typedef const __attribute__((address_space(4))) long long* plan_cptr_t;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-[[maybe_unused]] constexpr int kBStride = kBN + 16;                        // 144 doubles
+// Row stride of the B tile in LDS.  144 doubles (= 16 mod 32) puts k and k+1 on opposite bank halves: conflict-free fragment
+// reads.  Row tiles of up to 80 rows drop the padding: the stage shrinks from 28 to 26 KB, THREE workgroups fit a CU's 160 KB,
+// and the 4-way conflict on the two B fragment reads of a k-step (16 instead of 4 LDS clocks each, against 640 clocks of
+// MFMA issue) is hidden behind the third wave of every SIMD.
+constexpr int b_stride(int mi) { return mi <= 5 ? kBN : kBN + 16; }
 constexpr int a_stride(int bm) { return (bm % 32 == 16) ? bm : bm + 16; }
 
 // MI: row tile = 16*MI.  MUL: multiply into the parent panel instead of storing.  LEAF: what else the epilogue folds in --
@@ -63,10 +67,11 @@ constexpr int a_stride(int bm) { return (bm % 32 == 16) ? bm : bm + 16; }
 // reg its column, and a store instruction writes four columns x 16 consecutive rows = four full 128-byte lines of the
 // transposed factor, as wide as the row-major store of the other variants (32-byte pieces measured 8 % slower).
 template <int MI, bool MUL, int LEAF, bool TRANS = false>
-__global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI)) void prune_gemm_kernel(const GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the body uses amdgcn-only types (buffer resource); hipcc's host pass only needs the stub
     constexpr int BM = 16 * MI;
     constexpr int SA = a_stride(BM);
+    constexpr int kBStride = b_stride(MI);
     constexpr int A_TILE = kBK * SA, B_TILE = kBK * kBStride, STAGE = A_TILE + B_TILE;
     __shared__ double lds[2 * STAGE];
 
@@ -464,10 +469,11 @@ __global__ __launch_bounds__(256, 2) void prune_gemm_kernel(const GemmArgs a) {
 // are better off with lower tiles that fill their last round, while large ones want the tallest tile without row padding.
 // Lower tiles are a little less efficient per flop (80-row tiles: 68.2 against 69.9 TFLOP/s on full-width launches): 0.6 %
 // per step of MI.  tiles_by_mi[mi]: tiles of the whole group at that height.
-int prune_gemm_pick_mi(int64_t tiles_by_mi[10], int slots) {
+int prune_gemm_pick_mi(int64_t tiles_by_mi[10], int n_cu) {
     int best = 9;
     double best_cost = 1e300;
     for (int mi = 9; mi >= 4; --mi) {
+        const int slots = prune_gemm_wg_per_cu(mi) * n_cu / 8 * 8;
         const int64_t rounds = (tiles_by_mi[mi] + slots - 1) / slots;
         const double cost = (double)rounds * mi * (1.0 + 0.006 * (9 - mi));
         if (cost < best_cost * (1.0 - 1e-9)) { best_cost = cost; best = mi; }
@@ -475,11 +481,12 @@ int prune_gemm_pick_mi(int64_t tiles_by_mi[10], int slots) {
     return best;
 }
 
-// Persistent grid: two workgroups per CU (what the register/LDS budget admits), a multiple of 8 so that every XCD gets the
-// same number.  XCD x (blocks x, x+8, ...) owns the (category, column tile) pairs x, x+8, ... of every op of the launch and
-// its blocks share those pairs' row tiles: a small launch gets as many blocks per XCD as the busiest XCD (XCD 0) has tiles.
-int prune_gemm_blocks(int64_t tiles_xcd0, int n_cu) {
-    int blocks = std::min(2 * n_cu / 8 * 8, 512);        // (the planner deals with one lane per workgroup of an XCD: at most 64)
+// Persistent grid: as many workgroups per CU as are resident (the register/LDS budget admits three at up to 80-row tiles, two
+// above), a multiple of 8 so that every XCD gets the same number.  XCD x (blocks x, x+8, ...) owns the (category, column
+// tile) pairs x, x+8, ... of every op of the launch and its blocks share those pairs' row tiles: a small launch gets as
+// many blocks per XCD as the busiest XCD (XCD 0) has tiles.
+int prune_gemm_blocks(int64_t tiles_xcd0, int n_cu, int mi) {
+    int blocks = std::min(prune_gemm_wg_per_cu(mi) * n_cu / 8 * 8, 8 * kPlanLanes);     // (the planner deals with one lane per workgroup of an XCD)
     if (tiles_xcd0 * 8 < blocks) blocks = (int)(tiles_xcd0 * 8);
     return blocks < 8 ? 8 : blocks;
 }

@@ -755,6 +755,29 @@ def test_grouped_launches_equal_the_one_op_per_launch_schedule(capi, oracle, mon
 
 
 @pytest.mark.gpu
+def test_a_wide_tree_splits_its_levels_into_several_launches(capi, oracle):
+    """400 taxa: the level above the cherries holds more ops than one K2 launch carries (128 descriptors, 7 bits of a tile-list
+    entry) and more than one K3 launch (512): the groups are split, nothing else changes -- oracle parity, and the bits of the
+    one-op-per-launch schedule."""
+    import os
+    pb, _ = synth.make_problem(n_taxa=400, n_families=300, max_count=4, lam_sim=0.0005, seed=77, root_cap=2)   # (small counts: 400 factors per family must not underflow)
+    probs, mult = oracle.discrete_gamma(2, 1.5)
+    pr = P.Params(lambdas=np.array([0.0006]), prior=P.prior_uniform(pb.max_root_family_size), multipliers=mult, cat_probs=probs)
+    ctx = capi.Context(pb, max_categories=2)
+    v, r = ctx.score(pr, alpha=1.5, per_family=True)
+    assert rel_err(v, oracle.score(pb, pr)) <= SCORE_TOL
+    assert ctx.plan_check()[0] == ctx.stats()["gemm_launches"] > 0
+    os.environ["CAFE_NO_GROUPS"] = "1"
+    try:
+        single = capi.Context(pb, max_categories=2)
+    finally:
+        del os.environ["CAFE_NO_GROUPS"]
+    v2, r2 = single.score(pr, alpha=1.5, per_family=True)
+    assert v == v2 and all(np.array_equal(r[k], r2[k]) for k in r)
+    assert ctx.stats()["gemm_launches"] * 4 < single.stats()["gemm_launches"]
+
+
+@pytest.mark.gpu
 def test_bench_rank_path_under_a_launcher_with_one_rank():
     """What every rank of `bench.py --gpus N` does -- nccl process group, the communicator id over the launcher's channel,
     cafe_comm_attach, the all-reduce inside cafe_score, the max over ranks, detach -- on a one-GPU box: a world of ONE rank

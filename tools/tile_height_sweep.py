@@ -1,0 +1,23 @@
+"""Forced K2 tile heights (CAFE_FORCE_TILE) and planner constants at the bench shape: ms per call, same -lnL."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from cafexp_amd import capi, problem as P, synth
+from cafexp_amd.gamma_rates import discrete_gamma
+pb, _ = synth.make_problem(n_families=50000)
+probs, mult = discrete_gamma(8, 2.0)
+pr = P.Params(lambdas=np.array([0.002]), prior=P.prior_uniform(750), multipliers=mult, cat_probs=probs)
+for env in ({}, {"CAFE_FORCE_TILE": "4"}, {"CAFE_FORCE_TILE": "5"}, {"CAFE_FORCE_TILE": "7"}, {"CAFE_FORCE_TILE": "9"},
+            {"CAFE_PLAN_FIXED": "2"}, {"CAFE_PLAN_FIXED": "6"}, {}):
+    for k, v in env.items():
+        os.environ[k] = v
+    ctx = capi.Context(pb, max_categories=8)
+    for k in env:
+        del os.environ[k]
+    for _ in range(2):
+        v = ctx.score(pr, alpha=2.0)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        v = ctx.score(pr, alpha=2.0)
+    print(env, "%.2f ms" % ((time.perf_counter() - t0) / 5 * 1e3), v, flush=True)
+    ctx.close()
