@@ -75,7 +75,7 @@ hipError_t launch_node_extents(const ExtArgs& a, int max_col_tiles, int n_catego
     return hipGetLastError();
 }
 
-constexpr int kPlanTail = 3;
+constexpr int kPlanTail = 2;
 // Tile lists of the K2 launches of a call (PlanLaunch, cafe_kernels.h): one wave per (XCD, launch), lane = workgroup.
 // Cost of a tile = its K tiles + PlanLaunch::fixed.  With the full grid (64 workgroups per XCD) workgroups j and j + 32 share
 // a CU, and the one dispatched first (j < 32) wins the MFMA arbitration: given equal lists it ALWAYS finishes first, 8 % of
@@ -118,9 +118,11 @@ __device__ inline int2 plan_tile_entry(const PlanLaunch& L, const int* s_first, 
 // The rounds before them are dealt in chunks of kPlanChunk rounds, one wave per chunk (blockIdx.z), each balancing its own
 // rounds from a load of zero -- a launch of a whole tree level has hundreds of rounds, and one wave dealing them one after
 // the other took 1.8 ms in front of the first K2 launch of a config-4 call.
-constexpr int kPlanChunk = 32;
+constexpr int kPlanChunk = 8;
 __global__ __launch_bounds__(kPlanLanes) void tile_plan_kernel(const PlanLaunch* __restrict__ launches) {
-    const PlanLaunch& L = launches[blockIdx.y];
+    // (a copy in registers: the lists written below might alias the descriptor for all the compiler knows, and every field
+    // would be re-read from memory at each use -- the serial tail loop then paid a memory round trip per item)
+    const PlanLaunch L = launches[blockIdx.y];
     const int xcd = blockIdx.x, lane = threadIdx.x;         // lane = workgroup of the XCD (< blocks_per_xcd <= kPlanLanes)
     const int nlb = L.blocks_per_xcd;
     __shared__ int s_first[kMaxGroupOps + 1];
@@ -136,21 +138,26 @@ __global__ __launch_bounds__(kPlanLanes) void tile_plan_kernel(const PlanLaunch*
     __syncthreads();
     const int n_tiles = s_first[L.n_ops];
     // (two workgroups per CU, 64 per XCD: j and j + 32 share a CU and the first-dispatched one runs `bias` percent faster)
-    const int weight = (nlb == 64 && L.bias) ? (lane < 32 ? 100 - L.bias : 100 + L.bias) : 100;   // of this lane's workgroup
     __shared__ int s_load[kPlanLanes], s_cost[kPlanLanes], s_who[kPlanLanes];
-    __shared__ unsigned s_key[kPlanLanes];
     __shared__ int t_cost[kPlanTail * kPlanLanes], t_x[kPlanTail * kPlanLanes], t_y[kPlanTail * kPlanLanes], t_by_rank[kPlanTail * kPlanLanes];
     s_load[lane] = 0;
     __syncthreads();
     const int head = max(0, (n_tiles + nlb - 1) / nlb - kPlanTail);      // full rounds dealt one by one
     const int n_chunks = max(1, (head + kPlanChunk - 1) / kPlanChunk), chunk = blockIdx.z;
     if (chunk >= n_chunks) return;                          // (block-uniform: the grid is as deep as the launch with most rounds)
-    int2* __restrict__ mylist = L.plan + ((int64_t)xcd * nlb + lane) * L.rounds;   // (lanes < nlb)
-    for (int r = chunk * kPlanChunk; r < min(head, (chunk + 1) * kPlanChunk); ++r) {
-        const int t = r * nlb + lane;
-        const bool valid = lane < nlb;
-        int2 en = make_int2(0, 0);
-        if (valid) en = plan_tile_entry(L, s_first, xcd, t);
+    // the chunk's entries first, all at once (their extent look-ups are chains of dependent loads: one after the other they cost
+    // a memory round trip per round), then the rounds from LDS
+    __shared__ int c_x[kPlanChunk][kPlanLanes], c_y[kPlanChunk][kPlanLanes];
+    const int r_begin = chunk * kPlanChunk, r_end = min(head, (chunk + 1) * kPlanChunk);
+    const bool valid = lane < nlb;
+#pragma unroll
+    for (int i = 0; i < kPlanChunk; ++i)
+        if (valid && r_begin + i < r_end) {
+            const int2 en = plan_tile_entry(L, s_first, xcd, (r_begin + i) * nlb + lane);
+            c_x[i][lane] = en.x; c_y[i][lane] = en.y;
+        }
+    for (int r = r_begin; r < r_end; ++r) {
+        const int2 en = valid ? make_int2(c_x[r - r_begin][lane], c_y[r - r_begin][lane]) : make_int2(0, 0);
         const int cst = valid ? (en.y & 0xFFFF) + L.fixed : -1;
         const int mine = s_load[lane];
         s_cost[lane] = cst;
@@ -188,25 +195,35 @@ __global__ __launch_bounds__(kPlanLanes) void tile_plan_kernel(const PlanLaunch*
         t_by_rank[rank] = i;
     }
     __syncthreads();
-    int pos = head;
-    unsigned load = (unsigned)s_load[lane];
-    for (int q = 0; q < n_tail; ++q) {                      // each item, longest first, to the workgroup with the least load now
+    // each item, longest first, to the workgroup with the least load at that moment: a serial loop, run by the first wave alone
+    // (shuffles, no block barrier), lane j looking after workgroups j and j + 64
+    if (lane >= 64) return;
+    const int wg[2] = {lane, lane + 64};
+    int pos[2] = {head, head};
+    unsigned load[2] = {(unsigned)s_load[wg[0]], (unsigned)s_load[wg[1]]};
+    int wt[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) wt[h] = (nlb == 64 && L.bias) ? (wg[h] < 32 ? 100 - L.bias : 100 + L.bias) : 100;
+    for (int q = 0; q < n_tail; ++q) {
         const int item = t_by_rank[q];
-        s_key[lane] = (lane < nlb && pos < L.rounds) ? ((min(load, 0x00FFFFFFu) << 7) | (unsigned)lane) : 0xFFFFFFFFu;
-        __syncthreads();
-        for (int off = kPlanLanes / 2; off > 0; off >>= 1) {
-            if (lane < off) s_key[lane] = min(s_key[lane], s_key[lane + off]);
-            __syncthreads();
-        }
-        const unsigned key = s_key[0];
-        __syncthreads();
-        if (key != 0xFFFFFFFFu && lane == (int)(key & 127u)) {
-            mylist[pos++] = make_int2(t_x[item], t_y[item]);
-            load += (unsigned)(t_cost[item] * weight);
-        }
+        unsigned key = 0xFFFFFFFFu;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (wg[h] < nlb && pos[h] < L.rounds) key = min(key, (min(load[h], 0x00FFFFFFu) << 7) | (unsigned)wg[h]);
+        for (int off = 32; off > 0; off >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, off));
+        if (key == 0xFFFFFFFFu) break;                      // (no list has room: cannot happen, the lists have kPlanSlack spare entries)
+        const int w = (int)(key & 127u);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (w == wg[h]) {
+                L.plan[((int64_t)xcd * nlb + w) * L.rounds + pos[h]++] = make_int2(t_x[item], t_y[item]);
+                load[h] += (unsigned)(t_cost[item] * wt[h]);
+            }
     }
-    if (lane < nlb)
-        for (; pos < L.rounds; ++pos) mylist[pos] = make_int2(0, 0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        if (wg[h] < nlb)
+            for (; pos[h] < L.rounds; ++pos[h]) L.plan[((int64_t)xcd * nlb + wg[h]) * L.rounds + pos[h]] = make_int2(0, 0);
 }
 
 hipError_t launch_tile_plan(const PlanLaunch* d_launches, int n_launches, int max_rounds, hipStream_t stream) {
