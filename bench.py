@@ -58,8 +58,10 @@ def parse():
     ap.add_argument("--emulate-shard", default="", help="R/W: rehearsal on one GPU of what rank R of W would run (no collective)")
     ap.add_argument("--force-comm", action="store_true", help="diagnostic, under a launcher with ONE rank: take the N > 1 path (process group, "
                     "communicator inside the library, all-reduce in cafe_score) on a one-GPU box")
-    ap.add_argument("--shard-times", default="", help="with --emulate-shard: ms per shard measured under the default plan (comma list): "
-                    "use the plan rebalanced by them, as the ranks of an N > 1 run do after their first calls")
+    ap.add_argument("--shard-times", default="", help="with --emulate-shard: ms per shard measured under the default plan (comma list; "
+                    "several steps separated by ';': each measured under the plan the steps before it give): use the plan rebalanced by "
+                    "them, as the ranks of an N > 1 run do after their first calls")
+    ap.add_argument("--rebalance-steps", type=int, default=1, help="N > 1: steps of measured rebalancing during set-up (a second step measured no better: the residual 2 % is run-to-run noise)")
     ap.add_argument("--no-rebalance", dest="rebalance", action="store_false", help="N > 1: keep the predicted shard plan.  Default: one step "
                     "of measured rebalancing during set-up (every rank times a few calls of its predicted shard, the plan is corrected by the "
                     "gathered times)")
@@ -305,29 +307,34 @@ def main():
             er, ew = (int(x) for x in args.emulate_shard.split("/"))
             plan = capi.shard_plan(pb, ew, max(1, K))
             if args.shard_times:
-                plan = capi.rebalanced_plan(pb, plan, [float(x) for x in args.shard_times.split(",")], max(1, K))
-                plan_note = "rebalanced once from measured shard times"
+                scale = None
+                for step_times in args.shard_times.split(";"):
+                    plan, scale = capi.rebalanced_plan(pb, plan, [float(x) for x in step_times.split(",")], max(1, K), scale=scale, return_scale=True)
+                plan_note = "rebalanced %d time(s) from measured shard times" % len(args.shard_times.split(";"))
             mine = plan[er]
         elif dist_on:
             plan = capi.shard_plan(pb, world, max(1, K))
             if args.rebalance:
-                # One step of measured rebalancing, part of the set-up: what the prediction cannot see (how many K tiles the
-                # zero extents leave at these parameters) is in the time a shard's call takes.  Every rank times a few calls
-                # of its predicted shard, the times are gathered, every rank derives the same corrected plan.
-                probe = capi.Context(shard_of(plan[rank]), max_categories=max(1, K), device=device)
-                for _ in range(2):
-                    probe.score(pr, alpha=args.alpha)
-                t0p = time.perf_counter()
-                for _ in range(3):
-                    probe.score(pr, alpha=args.alpha)
-                mine_ms = (time.perf_counter() - t0p) / 3 * 1e3
-                probe.close()
-                tt = torch.zeros(world, dtype=torch.float64, device="cuda" if native_comm else "cpu")
-                tt[rank] = mine_ms
-                dist.all_reduce(tt)
-                times = [float(x) for x in tt.cpu().numpy()]
-                plan = capi.rebalanced_plan(pb, plan, times, max(1, K))
-                plan_note = "rebalanced once from measured shard times %s ms" % [round(x, 2) for x in times]
+                # Measured rebalancing, part of the set-up: what the prediction cannot see (how many K tiles the zero extents leave
+                # at these parameters) is in the time a shard's call takes.  Every rank times a few calls of its shard, the times
+                # are gathered, every rank derives the same corrected plan; a second step takes out most of what the first left.
+                scale, notes = None, []
+                for _step in range(max(1, args.rebalance_steps)):
+                    probe = capi.Context(shard_of(plan[rank]), max_categories=max(1, K), device=device)
+                    for _ in range(2):
+                        probe.score(pr, alpha=args.alpha)
+                    t0p = time.perf_counter()
+                    for _ in range(3):
+                        probe.score(pr, alpha=args.alpha)
+                    mine_ms = (time.perf_counter() - t0p) / 3 * 1e3
+                    probe.close()
+                    tt = torch.zeros(world, dtype=torch.float64, device="cuda" if native_comm else "cpu")
+                    tt[rank] = mine_ms
+                    dist.all_reduce(tt)
+                    times = [float(x) for x in tt.cpu().numpy()]
+                    plan, scale = capi.rebalanced_plan(pb, plan, times, max(1, K), scale=scale, return_scale=True)
+                    notes.append([round(x, 2) for x in times])
+                plan_note = "rebalanced %d time(s) from measured shard times %s ms" % (len(notes), notes)
             mine = plan[rank]
         else:
             mine = np.arange(F)

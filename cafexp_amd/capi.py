@@ -248,14 +248,17 @@ def shard_plan(pb: Problem, n_shards: int, max_categories: int = 1, family_scale
     return [order[bounds[r]:bounds[r + 1]].copy() for r in range(n_shards)]
 
 
-def rebalanced_plan(pb: Problem, plan, times, max_categories: int = 1):
+def rebalanced_plan(pb: Problem, plan, times, max_categories: int = 1, scale=None, return_scale: bool = False):
     """One step of measured rebalancing: `times[r]` is what shard r of `plan` took; the new plan (same number of shards) is
-    made with every family scaled by its shard's time over the mean."""
+    made with every family scaled by its shard's time over the mean -- on top of `scale` (per family, table order) when
+    `plan` itself came from an earlier step."""
     t = np.asarray(times, dtype=np.float64)
-    scale = np.ones(pb.n_families)
+    scale = np.ones(pb.n_families) if scale is None else np.array(scale, dtype=np.float64)
     for r, fam in enumerate(plan):
-        scale[fam] = t[r] / t.mean()
-    return shard_plan(pb, len(plan), max_categories, family_scale=scale)
+        scale[fam] *= t[r] / t.mean()
+    scale = np.clip(scale, 0.2, 5.0)
+    new = shard_plan(pb, len(plan), max_categories, family_scale=scale)
+    return (new, scale) if return_scale else new
 
 
 def comm_unique_id() -> bytes:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box from the repo root: what each rank of an N-way run would do, one shard after the other on the one GPU
 # (bench.py --emulate-shard r/N: the library's shard plan, no collective) -- first under the predicted plan, then under the
-# plan rebalanced once by the times just measured (what the ranks of an N > 1 run do during set-up).
+# plan rebalanced by the times just measured (what the ranks of an N > 1 run do during set-up), and once more.
 #   gpurun --timeout 1100 -- 'bash tools/shard_rehearsal.sh 8'
 set -e
 N=${1:-8}
@@ -21,4 +21,7 @@ PY
 echo "predicted plan"
 run_pass gpurun_out/shards_${N}_predicted.jsonl ""
 echo "rebalanced once from those times"
-run_pass gpurun_out/shards_$N.jsonl "--shard-times $(cat gpurun_out/.shard_times)"
+T1=$(cat gpurun_out/.shard_times)
+run_pass gpurun_out/shards_${N}_rebalanced1.jsonl "--shard-times $T1"
+echo "rebalanced a second time (--rebalance-steps 2)"
+run_pass gpurun_out/shards_$N.jsonl "--shard-times $T1;$(cat gpurun_out/.shard_times)"
