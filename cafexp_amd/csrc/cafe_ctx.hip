@@ -777,6 +777,10 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     // ---- launches: the ops of a step that share a kernel variant go out together
     if (const char* e = std::getenv("CAFE_PLAN_FIXED")) c->plan_fixed = std::max(0, atoi(e));
     if (const char* e = std::getenv("CAFE_PLAN_BIAS")) c->plan_bias = std::min(50, std::max(0, atoi(e)));
+    if (const char* e = std::getenv("CAFE_PLAN_BIAS3")) {
+        int a = 100, b = 100, d = 100;
+        if (std::sscanf(e, "%d,%d,%d", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0) { c->plan_bias3[0] = a; c->plan_bias3[1] = b; c->plan_bias3[2] = d; }
+    }
     {
         std::vector<size_t> idx(c->ops.size());
         for (size_t i = 0; i < idx.size(); ++i) idx[i] = i;
@@ -1084,6 +1088,7 @@ int prepare_descriptors(cafe_ctx* c, DescSet& ds, int K, int64_t cols, const std
         L.uniform_ld = c->subtree_dedup || c->grouped ? 0 : (int32_t)cols;
         L.mi = mi; L.n_categories = K; L.k_valid = c->M + 1;
         L.blocks_per_xcd = nlb; L.rounds = rounds; L.fixed = c->plan_fixed; L.bias = c->plan_bias;
+        for (int i = 0; i < 3; ++i) L.bias3[i] = c->plan_bias3[i];
         L.plan = ds.d_plan + used;
         ds.group_mi[gi] = mi; ds.group_blocks[gi] = blocks; ds.group_rounds[gi] = rounds; ds.group_plan_off[gi] = used;
         used += need;

@@ -126,6 +126,8 @@ struct PlanLaunch {
     int32_t rounds;                 // list length per workgroup
     int32_t fixed;                  // what an output tile costs beyond its K loop, in K tiles
     int32_t bias;                   // percent: the first-dispatched workgroup of a CU (local index < 32 of 64) runs that much faster
+    int32_t bias3[3];               // three workgroups per CU (96 per XCD; local indices j, j + 32, j + 64 share a CU): what a K tile costs
+                                    // the first / second / third dispatched one, in percent of the mean
     int2* plan;                     // [8][blocks_per_xcd][rounds]
 };
 constexpr int kPlanSlack = 2;       // spare list entries per workgroup (the planner's last rounds are dealt as one batch)

@@ -81,6 +81,16 @@ constexpr int kPlanTail = 2;
 // a CU, and the one dispatched first (j < 32) wins the MFMA arbitration: given equal lists it ALWAYS finishes first, 8 % of
 // the launch earlier, and the CU runs one workgroup to the end (tools/gemm_timeline.py).  The planner therefore charges a
 // tile `bias` percent less to j < 32 and as much more to j >= 32, so that the favoured workgroup takes more of the work.
+// What a K tile costs workgroup w of an XCD, in percent of the mean: the workgroups of a CU do not share its matrix pipe
+// evenly -- the one dispatched first wins the arbitration (with three per CU and equal lists they finish at 2 672 / 3 200 /
+// 3 503 us of a 3 563 us launch: tools/k2_tile_costs.py) -- so the planner charges the favoured ones less and they take more
+// of the work.  Full grids only (local indices j, j + 32, ... share a CU).
+__device__ inline int plan_weight(const PlanLaunch& L, int nlb, int w) {
+    if (nlb == 64 && L.bias) return w < 32 ? 100 - L.bias : 100 + L.bias;
+    if (nlb == 96) return L.bias3[w >> 5];
+    return 100;
+}
+
 // Tile t of XCD `xcd`'s list -- the concatenation of the lists of the launch's ops, each pair-major with the row tile
 // fastest (the order prune_gemm.hip's decode assumes) -- as a plan entry: x = op << 24 | index in the op's own list,
 // y = first K tile << 16 | K tiles.  s_first[o]: where op o's tiles start in the XCD's list (s_first[n_ops] = all).
@@ -173,8 +183,7 @@ __global__ __launch_bounds__(kPlanLanes) void tile_plan_kernel(const PlanLaunch*
         if (valid) {
             const int w = s_who[crank];
             L.plan[((int64_t)xcd * nlb + w) * L.rounds + r] = en;
-            const int ww = (nlb == 64 && L.bias) ? (w < 32 ? 100 - L.bias : 100 + L.bias) : 100;
-            s_load[w] += cst * ww;
+            s_load[w] += cst * plan_weight(L, nlb, w);
         }
         __syncthreads();
     }
@@ -203,7 +212,7 @@ __global__ __launch_bounds__(kPlanLanes) void tile_plan_kernel(const PlanLaunch*
     unsigned load[2] = {(unsigned)s_load[wg[0]], (unsigned)s_load[wg[1]]};
     int wt[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) wt[h] = (nlb == 64 && L.bias) ? (wg[h] < 32 ? 100 - L.bias : 100 + L.bias) : 100;
+    for (int h = 0; h < 2; ++h) wt[h] = plan_weight(L, nlb, wg[h]);
     for (int q = 0; q < n_tail; ++q) {
         const int item = t_by_rank[q];
         unsigned key = 0xFFFFFFFFu;

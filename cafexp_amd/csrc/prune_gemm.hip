@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI)) void prune_gemm_kern
     constexpr bool GATH = LEAF == 2;
     const int lda = a.pool.ld;
     const op_cptr_t ops = (op_cptr_t)(unsigned long long)a.ops;
-    unsigned long long st0 = 0, ep_ticks = 0, n_done = 0;
+    unsigned long long st0 = 0, ep_ticks = 0, n_done = 0, loop_ticks = 0, kt_done = 0, t_tile = 0;
     if (a.stamps) st0 = __builtin_amdgcn_s_memrealtime();
 
     // ---- persistent tile loop.  The grid is 2 workgroups per CU; a workgroup walks a fixed list of output
@@ -202,6 +202,7 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI)) void prune_gemm_kern
         const Tile cur = decode(e_cur);                     // scalar work, once per output tile; cheaper than carrying it
         const Tile nxt = decode(has_next ? e_nxt : e_cur);  // only its A/B descriptors and origins are used (DMA)
 
+        if (a.stamps) t_tile = __builtin_amdgcn_s_memrealtime();
         double4_t acc[MI][2];                               // zeroed while the first K tile is in flight
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI)) void prune_gemm_kern
             }
         };
         unsigned long long e0 = 0;
-        if (a.stamps) e0 = __builtin_amdgcn_s_memrealtime();
+        if (a.stamps) { e0 = __builtin_amdgcn_s_memrealtime(); loop_ticks += e0 - t_tile; kt_done += (unsigned long long)cur.nkt; }
         if (rows_here >= BM) epilogue(std::true_type{});
         else epilogue(std::false_type{});
         if (a.stamps) { ep_ticks += __builtin_amdgcn_s_memrealtime() - e0; n_done += 1; }
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI)) void prune_gemm_kern
         unsigned long long* o = a.stamps + 6 * (size_t)blockIdx.x;
         o[0] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
         o[1] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
-        o[2] = st0; o[3] = ep_ticks; o[4] = n_done; o[5] = __builtin_amdgcn_s_memrealtime();
+        o[2] = st0; o[3] = (ep_ticks & 0xFFFFFFFFull) | (loop_ticks << 32); o[4] = (n_done & 0xFFFFFull) | (kt_done << 20); o[5] = __builtin_amdgcn_s_memrealtime();
     }
 #else
     (void)a;
