@@ -549,7 +549,7 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
         c->stamps_launch = sl ? std::atol(sl) : -1;
         if (std::getenv("CAFE_USE_GRAPH")) c->use_graph = 1;
         const char* fm = std::getenv("CAFE_FORCE_TILE");             // diagnostic, like cafe_debug_force_tile
-        if (fm && std::atoi(fm) >= 4 && std::atoi(fm) <= 9) c->force_mi = std::atoi(fm);
+        if (fm && std::atoi(fm) >= 2 && std::atoi(fm) <= 9) c->force_mi = std::atoi(fm);
     }
 
     // outputs
@@ -877,7 +877,7 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
         for (const Group& g : c->groups) {
             if (g.type != 1) continue;
             size_t worst = 0;
-            for (int mi = 4; mi <= 9; ++mi) {
+            for (int mi = 2; mi <= 9; ++mi) {
                 int64_t tiles = 0;
                 for (int oi : g.ops) {
                     const Op& op = c->ops[oi];
@@ -1061,7 +1061,7 @@ int prepare_descriptors(cafe_ctx* c, DescSet& ds, int K, int64_t cols, const std
         if (!mi && prev_ext) mi = pick_tile_height(c, prev_ext->data(), g, K, cols);
         if (!mi) {                                          // no extents (yet): whole rounds x height
             int64_t tiles_by_mi[10] = {0};
-            for (int h = 4; h <= 9; ++h)
+            for (int h = 2; h <= 9; ++h)
                 for (int oi : g.ops) {
                     const Op& op = c->ops[oi];
                     const int64_t gc = c->subtree_dedup ? c->pat_cols[op.child] : cols;
@@ -1668,7 +1668,7 @@ int cafe_debug_stamps(cafe_ctx* ctx, unsigned long long* out, size_t words) {
 }
 
 int cafe_debug_force_tile(cafe_ctx* ctx, int mi) {
-    if (!ctx || (mi != 0 && (mi < 4 || mi > 9))) return CAFE_ERR_ARGUMENT;
+    if (!ctx || (mi != 0 && (mi < 2 || mi > 9))) return CAFE_ERR_ARGUMENT;
     ctx->force_mi = mi;
     return CAFE_OK;
 }

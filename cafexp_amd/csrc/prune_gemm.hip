@@ -105,13 +105,14 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI)) void prune_gemm_kern
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
                 int piece = q * 4 + wave + 16 * j;             // scalar
-                if (piece >= NP) piece -= NP;
+                while (piece >= NP) piece -= NP;               // (scalar; at most twice: NP >= 6)
                 // element e = 128*piece + 2*lane of the [16][BM] image -> (k-row, column).  128*piece splits on
                 // the scalar unit; adding 2*lane (<= 126 < 2*BM as BM >= 64) wraps at most twice
                 const int r0s = (piece * 128) / BM, c0s = (piece * 128) % BM;
                 int c = c0s + lane * 2, r = r0s;
                 if (c >= BM) { c -= BM; r += 1; }
                 if (c >= BM) { c -= BM; r += 1; }
+                if (BM < 64 && c >= BM) { c -= BM; r += 1; }        // (48-row tiles: 126 < 3 * 48)
                 a_voff[q][j] = (unsigned)((r * lda + c) * 8);
                 a_dst[q][j] = piece * 128;
             }
@@ -469,14 +470,18 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI)) void prune_gemm_kern
 // launch takes ceil(tiles / slots) rounds of one tile each, and a tile costs about MI (its MFMA count) -- so small launches
 // are better off with lower tiles that fill their last round, while large ones want the tallest tile without row padding.
 // Lower tiles are a little less efficient per flop (80-row tiles: 68.2 against 69.9 TFLOP/s on full-width launches): 0.6 %
-// per step of MI.  tiles_by_mi[mi]: tiles of the whole group at that height.
+// per step of MI.  tiles_by_mi[mi]: tiles of the whole group at that height.  Heights 2 and 3 (32 / 48 rows) exist for the
+// real-data regime (mammals: M = 140, 9 K tiles, a launch is ONE round of tiles and lasts as long as one tile: 18 us at 64
+// rows, of which 8 are the wave's 9 x 32 MFMAs).
 int prune_gemm_pick_mi(int64_t tiles_by_mi[10], int n_cu) {
     int best = 9;
     double best_cost = 1e300;
-    for (int mi = 9; mi >= 4; --mi) {
+    for (int mi = 9; mi >= 2; --mi) {
         const int slots = prune_gemm_wg_per_cu(mi) * n_cu / 8 * 8;
         const int64_t rounds = (tiles_by_mi[mi] + slots - 1) / slots;
-        const double cost = (double)rounds * mi * (1.0 + 0.006 * (9 - mi));
+        // (32- and 48-row tiles stage a B tile for few rows: only worth it when the launch is one round anyway -- the
+        // small-matrix regime, where a tile's latency is the launch's)
+        const double cost = (double)rounds * mi * (1.0 + 0.006 * (9 - mi) + (mi < 4 ? 0.2 * (4 - mi) : 0.0));
         if (cost < best_cost * (1.0 - 1e-9)) { best_cost = cost; best = mi; }
     }
     return best;
@@ -529,6 +534,8 @@ hipError_t launch_prune_gemm(const GemmArgs& a, GemmVariant v, int blocks, hipSt
     dim3 grid(blocks, 1, 1);
     (void)hipGetLastError();
     switch (a.mi) {
+        case 2: launch_mi<2>(a, v, grid, stream, ev0, ev1); break;
+        case 3: launch_mi<3>(a, v, grid, stream, ev0, ev1); break;
         case 4: launch_mi<4>(a, v, grid, stream, ev0, ev1); break;
         case 5: launch_mi<5>(a, v, grid, stream, ev0, ev1); break;
         case 6: launch_mi<6>(a, v, grid, stream, ev0, ev1); break;

@@ -273,7 +273,7 @@ int cafe_set_profiling(cafe_ctx* ctx, int on);
  * 0 (default; environment CAFE_USE_GRAPH at cafe_create turns it on): enqueue launch by launch.  Same kernels, same
  * arguments, same bits; which is faster depends on the runtime. */
 int cafe_set_graphs(cafe_ctx* ctx, int on);
-/* diagnostic: K2's row tile is 16*mi rows, mi = 4..9, normally chosen per launch; mi forces one, 0 restores the choice */
+/* diagnostic: K2's row tile is 16*mi rows, mi = 2..9, normally chosen per launch; mi forces one, 0 restores the choice */
 int cafe_debug_force_tile(cafe_ctx* ctx, int mi);
 /* test hook: the n-th next call of this context (n >= 1; 0 disarms) fails with CAFE_ERR_DEVICE behind its K1 launch, as a
  * HIP error in the middle of a call would -- pins the fail-together behaviour above */

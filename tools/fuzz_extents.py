@@ -36,7 +36,7 @@ for case in range(n_cases):
     for k in ("CAFE_NO_KSKIP", "CAFE_FORCE_TILE"):
         os.environ.pop(k, None)
     if rng.integers(0, 3) == 0:
-        os.environ["CAFE_FORCE_TILE"] = str(int(rng.choice([4, 6, 7, 8])))
+        os.environ["CAFE_FORCE_TILE"] = str(int(rng.choice([2, 3, 4, 6, 7, 8])))
     fast = capi.Context(pb, max_categories=8)
     os.environ.pop("CAFE_FORCE_TILE", None)
     os.environ["CAFE_NO_KSKIP"] = "1"
