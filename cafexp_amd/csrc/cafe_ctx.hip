@@ -558,7 +558,8 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     HIP_TRY(c, hipMalloc(&c->d_cat_out, sizeof(double) * c->Fp * c->Kmax));
     HIP_TRY(c, hipMalloc(&c->d_failed, sizeof(int32_t) * c->Fp));
     HIP_TRY(c, hipMemset(c->d_failed, 0, sizeof(int32_t) * c->Fp));
-    HIP_TRY(c, hipMalloc(&c->d_scratch, sizeof(double) * 2 * c->n_scratch));
+    HIP_TRY(c, hipMalloc(&c->d_scratch, sizeof(double) * (2 * c->n_scratch + 1)));      // partials + the ticket counter of the final sum
+    HIP_TRY(c, hipMemset(c->d_scratch, 0, sizeof(double) * (2 * c->n_scratch + 1)));
     HIP_TRY(c, hipMalloc(&c->d_result, sizeof(double) * 2));
     if (std::getenv("CAFE_GEMM_STAMPS")) {
         c->stamps_words = (size_t)6 * 8 * ((c->Fp / kBN + 8) * 16) * c->Kmax;

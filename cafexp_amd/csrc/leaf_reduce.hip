@@ -446,9 +446,14 @@ __device__ inline double block_sum(double v, double* sh) {
     return t;
 }
 
+// ... and the block that finishes last folds the partials, in index order whichever block that is (one launch instead of two:
+// in the small-matrix regime a call is the sum of its kernels' latencies).  scratch: [2 * blocks] partials, then one
+// unsigned counter (zero between calls: the folding block resets it).
+// out2: optionally a second copy, in host memory the device can write (the scorer's return value without a copy engine hop)
 __global__ __launch_bounds__(256) void partial_sum_kernel(const double* __restrict__ fam_out, const double* __restrict__ w,
-                                                          const int32_t* __restrict__ failed, int64_t n, double* scratch) {
+                                                          const int32_t* __restrict__ failed, int64_t n, double* scratch, double* out, double* out2) {
     __shared__ double sh[4];
+    __shared__ bool last;
     double s = 0.0, bad = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         s += w[i] * fam_out[i];
@@ -456,23 +461,26 @@ __global__ __launch_bounds__(256) void partial_sum_kernel(const double* __restri
     }
     const double ts = block_sum(s, sh);
     const double tb = block_sum(bad, sh);
+    unsigned* counter = reinterpret_cast<unsigned*>(scratch + 2 * gridDim.x);
     if (threadIdx.x == 0) {
         scratch[2 * blockIdx.x] = ts;
         scratch[2 * blockIdx.x + 1] = tb;
+        __threadfence();                                     // the partials are visible before the ticket is taken
+        last = atomicAdd(counter, 1u) == gridDim.x - 1;
     }
-}
-
-// out2: optionally a second copy, in host memory the device can write (the scorer's return value without a copy engine hop)
-__global__ __launch_bounds__(64) void fold_sum_kernel(const double* __restrict__ scratch, int n, double* out, double* out2) {
-    if (threadIdx.x != 0) return;
-    double s = 0.0, b = 0.0;
-    for (int i = 0; i < n; ++i) {
-        s += scratch[2 * i];
-        b += scratch[2 * i + 1];
+    __syncthreads();
+    if (!last || threadIdx.x != 0) return;
+    __threadfence();
+    double fs = 0.0, fb = 0.0;
+    const volatile double* sc = scratch;                     // (written by other blocks of this launch)
+    for (unsigned i = 0; i < gridDim.x; ++i) {
+        fs += sc[2 * i];
+        fb += sc[2 * i + 1];
     }
-    out[0] = s;
-    out[1] = b;
-    if (out2) { out2[0] = s; out2[1] = b; }
+    out[0] = fs;
+    out[1] = fb;
+    if (out2) { out2[0] = fs; out2[1] = fb; }
+    *counter = 0u;
 }
 
 hipError_t launch_final_sum(const double* fam_out, const double* weights, const int32_t* failed, int64_t n,
@@ -481,9 +489,7 @@ hipError_t launch_final_sum(const double* fam_out, const double* weights, const 
     if (blocks > n_scratch) blocks = n_scratch;
     if (blocks < 1) blocks = 1;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(partial_sum_kernel, dim3(blocks), dim3(256), 0, stream, fam_out, weights, failed, n, scratch);
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(fold_sum_kernel, dim3(1), dim3(64), 0, stream, scratch, blocks, out, out_host);
+    hipLaunchKernelGGL(partial_sum_kernel, dim3(blocks), dim3(256), 0, stream, fam_out, weights, failed, n, scratch, out, out_host);
     return hipGetLastError();
 }
 
