@@ -365,6 +365,47 @@ def test_config4_shape_properties(capi, oracle):
     assert rel_err(capi.Context(doubled, max_categories=8).score(pr, alpha=2.0), 2 * whole) <= 1e-12
 
 
+def test_config4_and_config5_at_full_size(capi, oracle):
+    """BASELINE configs 4 and 5 at their FULL sizes (50 000 families x K = 8; 100 000 families, two lambdas, 3-tap error
+    model), through properties that do not need the oracle at that size: the whole table's per-family values are, bit for
+    bit, those of the two shards of the library's plan (other distinct-column sets, other tile lists, other launch groups),
+    the shard sums add up to the whole, a second call repeats the first, and a sample of families meets the CPU restatement."""
+    from cafexp_amd import synth
+    for cfg in (4, 5):
+        if cfg == 4:
+            pb, _ = synth.make_problem(n_families=50000)
+            probs, mult = oracle.discrete_gamma(8, 2.0)
+            pr, alpha, K = P.Params(lambdas=np.array([0.002]), prior=P.prior_uniform(750), multipliers=mult, cat_probs=probs), 2.0, 8
+        else:
+            pb, _ = synth.make_problem(n_families=100000, lambda_clade_min=10, n_deviations=3)
+            em = P.error_model_table(P.default_error_model(pb.max_family_size)[:1] + [[0.05, 0.9, 0.05]], pb.max_family_size)
+            pr, alpha, K = P.Params(lambdas=np.array([0.002, 0.004]), prior=P.prior_uniform(750), error_model=em), 1.0, 1
+        assert (pb.max_family_size, pb.max_root_family_size, pb.matrix_size) == (720, 750, 751)
+        key = "family_likelihood" if cfg == 4 else "family_lnl"
+        ctx = capi.Context(pb, max_categories=K)
+        whole, res = ctx.score(pr, alpha=alpha, per_family=True)
+        again, res2 = ctx.score(pr, alpha=alpha, per_family=True)
+        assert math.isfinite(whole) and whole == again and np.array_equal(res[key], res2[key])
+        ctx.close()
+        parts = 0.0
+        for idx in capi.shard_plan(pb, 2, K):
+            shard = dataclasses.replace(pb, counts=np.ascontiguousarray(pb.counts[idx]), family_ids=[pb.family_ids[i] for i in idx])
+            sc = capi.Context(shard, max_categories=K)
+            v, r = sc.score(pr, alpha=alpha, per_family=True)
+            assert np.array_equal(r[key], res[key][idx])
+            parts += v
+            sc.close()
+        assert rel_err(parts, whole) <= 1e-12
+        sel = np.array([0, 7, 4999, 25000, pb.n_families - 1])
+        sub = dataclasses.replace(pb, counts=pb.counts[sel].copy(), family_ids=[pb.family_ids[i] for i in sel])
+        if cfg == 4:
+            _, cat, fam = oracle.score_gamma(sub, pr, fast=True, per_family=True)
+            assert np.abs(res["family_likelihood"][sel] / fam - 1).max() <= VEC_TOL
+        else:
+            _, fam = oracle.score_base(sub, pr, fast=True, per_family=True)
+            assert np.abs(res["family_lnl"][sel] / fam - 1).max() <= SCORE_TOL
+
+
 def test_five_tap_error_model_and_mixed_leaf_counts(capi, oracle):
     """cntdiff -2..2 (error_model::set_deviations is general, error_model.cpp:18-31): no fused or fast path applies,
     the generic gather does; also a parent with three leaf children next to an interior one."""
