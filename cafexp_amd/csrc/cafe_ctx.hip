@@ -778,6 +778,11 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     // ---- launches: the ops of a step that share a kernel variant go out together
     if (const char* e = std::getenv("CAFE_PLAN_FIXED")) c->plan_fixed = std::max(0, atoi(e));
     if (const char* e = std::getenv("CAFE_PLAN_BIAS")) c->plan_bias = std::min(50, std::max(0, atoi(e)));
+    if (const char* e = std::getenv("CAFE_PLAN_BIAS4")) {
+        int v[4];
+        if (std::sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0)
+            for (int i = 0; i < 4; ++i) c->plan_bias4[i] = v[i];
+    }
     if (const char* e = std::getenv("CAFE_PLAN_BIAS3")) {
         int a = 100, b = 100, d = 100;
         if (std::sscanf(e, "%d,%d,%d", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0) { c->plan_bias3[0] = a; c->plan_bias3[1] = b; c->plan_bias3[2] = d; }
@@ -1007,7 +1012,7 @@ int pick_tile_height(const cafe_ctx* c, const int32_t* ext, const Group& g, int 
     static const double eff[10] = {0, 0, 0, 0, 1.12, 1.03, 1.30, 1.06, 1.05, 1.00};
     const int nb = c->kpool.ext_blocks;
     const int n_k = (c->M + 1 + kBK - 1) / kBK;
-    const double overhead = 2.0;             // prologue + epilogue of a tile, in K tiles
+    const double overhead = 2.0 * 16 / kBK;  // prologue + epilogue of a tile, in K tiles
     int best = 9;
     double best_cost = 1e300;
     for (int mi = 9; mi >= 4; --mi) {
@@ -1089,7 +1094,7 @@ int prepare_descriptors(cafe_ctx* c, DescSet& ds, int K, int64_t cols, const std
         L.uniform_ld = c->subtree_dedup || c->grouped ? 0 : (int32_t)cols;
         L.mi = mi; L.n_categories = K; L.k_valid = c->M + 1;
         L.blocks_per_xcd = nlb; L.rounds = rounds; L.fixed = c->plan_fixed; L.bias = c->plan_bias;
-        for (int i = 0; i < 3; ++i) L.bias3[i] = c->plan_bias3[i];
+        for (int i = 0; i < 4; ++i) L.bias3[i] = nlb == 128 ? c->plan_bias4[i] : (i < 3 ? c->plan_bias3[i] : 100);
         L.plan = ds.d_plan + used;
         ds.group_mi[gi] = mi; ds.group_blocks[gi] = blocks; ds.group_rounds[gi] = rounds; ds.group_plan_off[gi] = used;
         used += need;

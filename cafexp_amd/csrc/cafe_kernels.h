@@ -17,7 +17,7 @@ constexpr int kMaxLeafPerOp = 4;     // leaf children folded by one gather launc
 
 // GEMM tiling (fp64 MFMA 16x16x4): block tile (16*MI) x 128, K step 16, 4 waves side by side in N
 constexpr int kBN = 128;
-constexpr int kBK = 16;
+constexpr int kBK = 8;           // depth of a K tile: two k-steps of the 16x16x4 MFMA (16 until round 3: half the LDS per stage now)
 constexpr int kMaxBM = 144;          // largest row tile (MI = 9)
 
 // Per transition matrix: a = lambda_q t_q / (1 + lambda_q t_q) of the de-quantized key
@@ -126,8 +126,8 @@ struct PlanLaunch {
     int32_t rounds;                 // list length per workgroup
     int32_t fixed;                  // what an output tile costs beyond its K loop, in K tiles
     int32_t bias;                   // percent: the first-dispatched workgroup of a CU (local index < 32 of 64) runs that much faster
-    int32_t bias3[3];               // three workgroups per CU (96 per XCD; local indices j, j + 32, j + 64 share a CU): what a K tile costs
-                                    // the first / second / third dispatched one, in percent of the mean
+    int32_t bias3[4];               // three or four workgroups per CU (96 / 128 per XCD; local indices j, j + 32, ... share a CU): what a K
+                                    // tile costs the first / second / ... dispatched one, in percent of the mean
     int2* plan;                     // [8][blocks_per_xcd][rounds]
 };
 constexpr int kPlanSlack = 2;       // spare list entries per workgroup (the planner's last rounds are dealt as one batch)
@@ -135,7 +135,7 @@ constexpr int kPlanSlack = 2;       // spare list entries per workgroup (the pla
 hipError_t launch_tile_plan(const PlanLaunch* d_launches, int n_launches, int max_rounds, hipStream_t stream);
 // Workgroups of K2 resident on a CU: three for row tiles of up to 80 rows (52 KB of LDS each with an unpadded B tile, <= 168
 // vector registers), two for the taller ones (up to 72 KB, <= 250 registers).
-constexpr int prune_gemm_wg_per_cu(int mi) { return mi <= 5 ? 3 : 2; }
+constexpr int prune_gemm_wg_per_cu(int mi) { return mi <= 5 ? 4 : 2; }
 constexpr int kPlanLanes = 128;     // workgroups of an XCD the tile planner can deal to (32 CUs x 3 = 96 on MI355X)
 // workgroups of a K2 launch (a multiple of 8) whose busiest XCD owns `tiles_xcd0` tiles: as many as are resident, fewer when there are fewer tiles
 int prune_gemm_blocks(int64_t tiles_xcd0, int n_cu, int mi);

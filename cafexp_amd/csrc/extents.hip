@@ -87,7 +87,7 @@ constexpr int kPlanTail = 2;
 // of the work.  Full grids only (local indices j, j + 32, ... share a CU).
 __device__ inline int plan_weight(const PlanLaunch& L, int nlb, int w) {
     if (nlb == 64 && L.bias) return w < 32 ? 100 - L.bias : 100 + L.bias;
-    if (nlb == 96) return L.bias3[w >> 5];
+    if (nlb == 96 || nlb == 128) return L.bias3[w >> 5];
     return 100;
 }
 

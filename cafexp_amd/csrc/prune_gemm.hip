@@ -96,15 +96,17 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI)) void prune_gemm_kern
 
     // per-lane constants that do not depend on the tile (tile origins travel in the scalar offsets)
     constexpr bool A_CONTIG = (SA == BM);
-    constexpr int NP = 2 * MI, PER = (NP + 15) / 16;
-    unsigned a_voff[4][PER > 0 ? PER : 1];       // bytes
-    int a_dst[4][PER > 0 ? PER : 1];
+    constexpr int NS = kBK / 4;                    // k-steps of a K tile = DMA "quarters" of a stage (4 k-rows each, one per wave)
+    constexpr int SLOTS = 4 * NS;
+    constexpr int NP = kBK * BM / 128, PER = (NP + SLOTS - 1) / SLOTS;     // 1 KB pieces of the contiguous [kBK][BM] A image
+    unsigned a_voff[NS][PER > 0 ? PER : 1];      // bytes
+    int a_dst[NS][PER > 0 ? PER : 1];
     if (A_CONTIG) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NS; ++q)
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
-                int piece = q * 4 + wave + 16 * j;             // scalar
+                int piece = q * 4 + wave + SLOTS * j;          // scalar
                 while (piece >= NP) piece -= NP;               // (scalar; at most twice: NP >= 6)
                 // element e = 128*piece + 2*lane of the [16][BM] image -> (k-row, column).  128*piece splits on
                 // the scalar unit; adding 2*lane (<= 126 < 2*BM as BM >= 64) wraps at most twice
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI)) void prune_gemm_kern
     {
         const Tile first = decode(e_cur);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) stage_quarter(first, first.kt0 * kBK, 0, q);
+        for (int q = 0; q < NS; ++q) stage_quarter(first, first.kt0 * kBK, 0, q);
     }
     int g = 0;                                              // running K-tile count: stage parity
     __syncthreads();                                        // vmcnt(0) + barrier: the first K tile has landed (later
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI)) void prune_gemm_kern
             read_b(base, 0, bfr[0]);
         }
         const int nkt = cur.nkt, kbase = cur.kt0 * kBK;     // this tile's K tiles: kbase, kbase + 16, ...
-        const int steps_last = cur.kt0 + nkt == n_k ? last_steps : 4;   // only the matrix's last K tile is ragged
+        const int steps_last = cur.kt0 + nkt == n_k ? last_steps : NS;  // only the matrix's last K tile is ragged
         for (int kt = 0; kt + 1 < nkt; ++kt) {
             const int buf = g & 1;
             const double* base = lds + buf * STAGE;
@@ -240,8 +242,8 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI)) void prune_gemm_kern
             const int k1 = kbase + (kt + 1) * kBK;          // K tile being staged into the other stage
             const bool next_full = kt + 2 < nkt;            // K tile kt+1 is another pipelined one (not this tile's last)
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                if (s4 < 3) {
+            for (int s4 = 0; s4 < NS; ++s4) {
+                if (s4 < NS - 1) {
                     if (s4 == 0 && kt == 0) stage_quarter(cur, k1, buf ^ 1, 0);   // no earlier step to carry it
                     stage_quarter(cur, k1, buf ^ 1, s4 + 1);
                 } else {
@@ -249,9 +251,9 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI)) void prune_gemm_kern
                     if (next_full) stage_quarter(cur, k1 + kBK, buf, 0);
                     else if (has_next) stage_quarter(nxt, nxt.kt0 * kBK, buf, 0);
                 }
-                const bool pre = s4 < 3 || next_full;       // uniform
-                const double* src = s4 < 3 ? base : nbase;
-                const int ns = (s4 + 1) & 3;
+                const bool pre = s4 < NS - 1 || next_full;  // uniform
+                const double* src = s4 < NS - 1 ? base : nbase;
+                const int ns = (s4 + 1) % NS;
                 if (pre) read_b(src, ns, bfr[(s4 + 1) & 1]);
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
@@ -275,12 +277,11 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI)) void prune_gemm_kern
             if (has_next) {
                 const int nk0 = nxt.kt0 * kBK;
                 if (nkt == 1) stage_quarter(nxt, nk0, buf ^ 1, 0);
-                stage_quarter(nxt, nk0, buf ^ 1, 1);
-                stage_quarter(nxt, nk0, buf ^ 1, 2);
-                stage_quarter(nxt, nk0, buf ^ 1, 3);
+#pragma unroll
+                for (int q = 1; q < NS; ++q) stage_quarter(nxt, nk0, buf ^ 1, q);
             }
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
+            for (int s4 = 0; s4 < NS; ++s4) {
                 if (s4 < steps_last) {
 #pragma unroll
                     for (int i = 0; i < MI; ++i) af[i] = base[a_off + s4 * 4 * SA + i * 16];
@@ -396,7 +397,8 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI)) void prune_gemm_kern
             }
         };
         auto epilogue = [&](auto full) {
-            constexpr int NB = LEAF == 3 ? 1 : 2;           // the 3-tap variant has no registers left for a second set
+            // (a second set of prefetched operands only where the register budget has room: not with four waves per SIMD)
+            constexpr int NB = (LEAF == 3 || prune_gemm_wg_per_cu(MI) >= 4) ? 1 : 2;
             Pre pre[NB];
             if (MUL || LEAF) prefetch(0, pre[0], full);
             // full unroll is mandatory: a runtime i would index the accumulator array dynamically and demote

@@ -11,6 +11,8 @@ sweeps = ({}, {"CAFE_FORCE_TILE": "4"}, {"CAFE_FORCE_TILE": "5"}, {"CAFE_FORCE_T
           {"CAFE_PLAN_FIXED": "2"}, {"CAFE_PLAN_FIXED": "6"}, {})
 if len(sys.argv) > 1 and sys.argv[1] == "bias3":
     sweeps = tuple({"CAFE_PLAN_BIAS3": v} for v in (sys.argv[2:] or ["100,100,100", "89,103,110", "83,105,116", "78,106,124"]))
+if len(sys.argv) > 1 and sys.argv[1] == "bias4":
+    sweeps = tuple({"CAFE_PLAN_BIAS4": v} for v in sys.argv[2:])
 for env in sweeps:
     for k, v in env.items():
         os.environ[k] = v
