@@ -207,7 +207,8 @@ struct cafe_ctx {
     int plan_bias = 8;                       // percent by which the first-dispatched workgroup of a CU outruns the other (measured; CAFE_PLAN_BIAS)
     int plan_bias3[3] = {80, 100, 125};      // three workgroups per CU: cost of a K tile for the first / second / third dispatched (CAFE_PLAN_BIAS3=a,b,c)
     int plan_bias4[4] = {62, 88, 112, 160};  // four (CAFE_PLAN_BIAS4=a,b,c,d)
-    int plan_fixed = 8;                      // cost of an output tile beyond its K loop, in K tiles (fitted: DESIGN.md; CAFE_PLAN_FIXED)
+    int kb = 8;                              // depth of K2's K tiles: 8 (four workgroups per CU) or 16 (small matrices); CAFE_KB
+    int plan_fixed = 8;                      // cost of an output tile beyond its K loop, in 8-deep K tiles (fitted: DESIGN.md; CAFE_PLAN_FIXED)
     size_t plan_entries = 0;
     cafe::PlanLaunch* h_plan_desc = nullptr;        // pinned
     const cafe::DescSet* desc_last = nullptr;       // descriptors of the last recorded call (diagnostics)

@@ -548,6 +548,10 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
         const char* sl = std::getenv("CAFE_GEMM_STAMPS_LAUNCH");       // diagnostics: read once, never on the call path
         c->stamps_launch = sl ? std::atol(sl) : -1;
         if (std::getenv("CAFE_USE_GRAPH")) c->use_graph = 1;
+        // small matrices (a K2 launch is one round of tiles and lasts as long as one tile): 16-deep K tiles, half as many DMA
+        // round trips per tile; otherwise 8-deep ones, four workgroups per CU
+        c->kb = c->N < 256 ? 16 : 8;
+        if (const char* e = std::getenv("CAFE_KB")) c->kb = std::atoi(e) == 16 ? 16 : 8;
         const char* fm = std::getenv("CAFE_FORCE_TILE");             // diagnostic, like cafe_debug_force_tile
         if (fm && std::atoi(fm) >= 2 && std::atoi(fm) <= 9) c->force_mi = std::atoi(fm);
     }
@@ -1011,13 +1015,14 @@ bool rejected(const cafe_ctx* c, const cafe_params* pr, int K) {
 int pick_tile_height(const cafe_ctx* c, const int32_t* ext, const Group& g, int K, int64_t chunk_cols) {
     static const double eff[10] = {0, 0, 0, 0, 1.12, 1.03, 1.30, 1.06, 1.05, 1.00};
     const int nb = c->kpool.ext_blocks;
+    const int kBK = c->kb;
     const int n_k = (c->M + 1 + kBK - 1) / kBK;
     const double overhead = 2.0 * 16 / kBK;  // prologue + epilogue of a tile, in K tiles
     int best = 9;
     double best_cost = 1e300;
     for (int mi = 9; mi >= 4; --mi) {
         if (mi == 6) continue;
-        const int slots = prune_gemm_wg_per_cu(mi) * c->n_cu / 8 * 8;
+        const int slots = prune_gemm_wg_per_cu(mi, c->kb) * c->n_cu / 8 * 8;
         double work = 0, tiles = 0;          // sum over (op, category, row tile, column tile) of (K tiles + overhead) * height; tiles
         for (int oi : g.ops) {
             const Op& op = c->ops[oi];
@@ -1073,7 +1078,7 @@ int prepare_descriptors(cafe_ctx* c, DescSet& ds, int K, int64_t cols, const std
                     const int64_t gc = c->subtree_dedup ? c->pat_cols[op.child] : cols;
                     tiles_by_mi[h] += (int64_t)(((op.to_root ? c->R : c->M) + 16 * h - 1) / (16 * h)) * (gc / kBN) * K;
                 }
-            mi = prune_gemm_pick_mi(tiles_by_mi, c->n_cu);
+            mi = prune_gemm_pick_mi(tiles_by_mi, c->n_cu, c->kb);
         }
         int64_t tiles0 = 0;
         for (int oi : g.ops) {
@@ -1083,7 +1088,7 @@ int prepare_descriptors(cafe_ctx* c, DescSet& ds, int K, int64_t cols, const std
             const int64_t gc = c->subtree_dedup ? c->pat_cols[op.child] : cols;
             tiles0 += prune_gemm_tiles_xcd0(K, (int)(gc / kBN), d.n_row_tiles);
         }
-        const int blocks = prune_gemm_blocks(tiles0, c->n_cu, mi), nlb = blocks / 8;
+        const int blocks = prune_gemm_blocks(tiles0, c->n_cu, mi, c->kb), nlb = blocks / 8;
         const int rounds = (int)((tiles0 + nlb - 1) / nlb) + kPlanSlack;
         const size_t need = (size_t)8 * nlb * rounds;
         if (used + need > c->plan_entries) { set_err(c, "internal: tile lists do not fit (%zu + %zu > %zu)", used, need, c->plan_entries); return CAFE_ERR_STATE; }
@@ -1092,8 +1097,8 @@ int prepare_descriptors(cafe_ctx* c, DescSet& ds, int K, int64_t cols, const std
         L.aext = c->kpool.ext; L.ext_blocks = c->kpool.ext_blocks;
         L.ops = ds.d_gemm_ops + g.first_desc; L.n_ops = (int)g.ops.size();
         L.uniform_ld = c->subtree_dedup || c->grouped ? 0 : (int32_t)cols;
-        L.mi = mi; L.n_categories = K; L.k_valid = c->M + 1;
-        L.blocks_per_xcd = nlb; L.rounds = rounds; L.fixed = c->plan_fixed; L.bias = c->plan_bias;
+        L.mi = mi; L.n_categories = K; L.k_valid = c->M + 1; L.kb = c->kb;
+        L.blocks_per_xcd = nlb; L.rounds = rounds; L.fixed = std::max(1, c->plan_fixed * 8 / c->kb); L.bias = c->plan_bias;
         for (int i = 0; i < 4; ++i) L.bias3[i] = nlb == 128 ? c->plan_bias4[i] : (i < 3 ? c->plan_bias3[i] : 100);
         L.plan = ds.d_plan + used;
         ds.group_mi[gi] = mi; ds.group_blocks[gi] = blocks; ds.group_rounds[gi] = rounds; ds.group_plan_off[gi] = used;
@@ -1211,7 +1216,7 @@ int record_call(cafe_ctx* c, DescSet& ds, int K, bool gamma, bool rootmax, bool 
             GemmArgs a{};
             a.pool = c->kpool; a.lpool = c->pool;
             a.ops = ds.d_gemm_ops + g.first_desc; a.n_ops = (int)g.ops.size();
-            a.k_valid = c->M + 1; a.mi = ds.group_mi[gi]; a.n_categories = K;
+            a.k_valid = c->M + 1; a.kb = c->kb; a.mi = ds.group_mi[gi]; a.n_categories = K;
             a.uniform_ld = uniform_ld;
             a.f0 = c->subtree_dedup ? 0 : f0;
             a.err = use_err ? c->d_err : nullptr; a.max_family_size = c->M;
@@ -1362,6 +1367,7 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bo
 // the extents back (a few synchronous copies, milliseconds of host work): for measurement, once, not per call.
 double count_executed_flops(cafe_ctx* c, std::vector<double>* per_launch = nullptr) {
     if (c->gemm_launches_info.empty()) return c->stats.gemm_flops;
+    const int kBK = c->kb;
     const int nb = c->kpool.ext_blocks;
     std::vector<int32_t> ext;
     if (c->kpool.ext) {
@@ -1805,7 +1811,7 @@ int cafe_debug_plan_check(cafe_ctx* ctx, int32_t* n_planned, double* worst_load)
                         if (hi < lo) { lo = zlo; hi = zlo; }
                         hi = std::min(hi, L.k_valid - 1);
                     }
-                    if ((e.y >> 16) != lo / kBK || (e.y & 0xFFFF) != hi / kBK - lo / kBK + 1) goto bad;
+                    if ((e.y >> 16) != lo / L.kb || (e.y & 0xFFFF) != hi / L.kb - lo / L.kb + 1) goto bad;
                     load += (e.y & 0xFFFF) + L.fixed;
                 }
                 total += load;

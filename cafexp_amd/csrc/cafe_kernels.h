@@ -17,7 +17,9 @@ constexpr int kMaxLeafPerOp = 4;     // leaf children folded by one gather launc
 
 // GEMM tiling (fp64 MFMA 16x16x4): block tile (16*MI) x 128, K step 16, 4 waves side by side in N
 constexpr int kBN = 128;
-constexpr int kBK = 8;           // depth of a K tile: two k-steps of the 16x16x4 MFMA (16 until round 3: half the LDS per stage now)
+constexpr int kBK = 16;          // largest depth of a K tile (panel / matrix row counts are rounded to it); a context runs K2 with 16-deep
+                                 // K tiles (small matrices: a launch is one round of tiles, fewer DMA round trips per tile) or 8-deep ones
+                                 // (half the LDS per stage: four workgroups per CU) -- GemmArgs::kb
 constexpr int kMaxBM = 144;          // largest row tile (MI = 9)
 
 // Per transition matrix: a = lambda_q t_q / (1 + lambda_q t_q) of the de-quantized key
@@ -94,6 +96,7 @@ struct GemmArgs {
     const GemmOp* ops;              // the group's descriptors (device memory)
     int32_t n_ops;
     int32_t k_valid;                // contraction extent M+1
+    int32_t kb;                     // depth of a K tile: 8 or 16
     int32_t mi;                     // row tile = 16*mi, the same for every op of the launch
     int32_t n_categories;
     int32_t uniform_ld;             // > 0 (several column chunks, one column per family): columns of every panel in this chunk;
@@ -122,6 +125,7 @@ struct PlanLaunch {
     int32_t n_ops;
     int32_t uniform_ld;             // as GemmArgs
     int32_t mi, n_categories, k_valid;
+    int32_t kb;                     // depth of a K tile (GemmArgs::kb)
     int32_t blocks_per_xcd;         // workgroups of the launch / 8
     int32_t rounds;                 // list length per workgroup
     int32_t fixed;                  // what an output tile costs beyond its K loop, in K tiles
@@ -133,12 +137,13 @@ struct PlanLaunch {
 constexpr int kPlanSlack = 2;       // spare list entries per workgroup (the planner's last rounds are dealt as one batch)
 // max_rounds: the longest PlanLaunch::rounds of the launches (the planner's grid depth)
 hipError_t launch_tile_plan(const PlanLaunch* d_launches, int n_launches, int max_rounds, hipStream_t stream);
-// Workgroups of K2 resident on a CU: three for row tiles of up to 80 rows (52 KB of LDS each with an unpadded B tile, <= 168
-// vector registers), two for the taller ones (up to 72 KB, <= 250 registers).
-constexpr int prune_gemm_wg_per_cu(int mi) { return mi <= 5 ? 4 : 2; }
+// Workgroups of K2 resident on a CU.  Row tiles of up to 80 rows: four with 8-deep K tiles (26 KB of LDS each, 128 vector
+// registers), three with 16-deep ones (52 KB with an unpadded B tile, <= 168 registers); the taller ones: two (<= 250
+// registers).
+constexpr int prune_gemm_wg_per_cu(int mi, int kb) { return mi <= 5 ? (kb <= 8 ? 4 : 3) : 2; }
 constexpr int kPlanLanes = 128;     // workgroups of an XCD the tile planner can deal to (32 CUs x 3 = 96 on MI355X)
 // workgroups of a K2 launch (a multiple of 8) whose busiest XCD owns `tiles_xcd0` tiles: as many as are resident, fewer when there are fewer tiles
-int prune_gemm_blocks(int64_t tiles_xcd0, int n_cu, int mi);
+int prune_gemm_blocks(int64_t tiles_xcd0, int n_cu, int mi, int kb);
 // tiles XCD 0 owns of an op with n_pairs = categories * column tiles
 inline int64_t prune_gemm_tiles_xcd0(int n_categories, int n_col_tiles, int n_row_tiles) {
     return (((int64_t)n_categories * n_col_tiles + 7) / 8) * n_row_tiles;
@@ -226,7 +231,7 @@ hipError_t launch_bd_matrix_build_both(const MatrixPool& pool, const MatrixPool&
 struct GemmVariant { int mode, leaf, trans; };
 hipError_t launch_prune_gemm(const GemmArgs& a, GemmVariant v, int blocks, hipStream_t stream, hipEvent_t ev_start = nullptr,
                              hipEvent_t ev_stop = nullptr);
-int prune_gemm_pick_mi(int64_t row_tile_pairs_by_mi[10], int n_cu);     // row-tile height (in 16-row blocks) from the group's tile counts per height
+int prune_gemm_pick_mi(int64_t row_tile_pairs_by_mi[10], int n_cu, int kb);     // row-tile height (in 16-row blocks) from the group's tile counts per height
 // what a K3 launch of a group of ops shares
 struct GatherGroup {
     MatrixPool pool;                // row-major pool

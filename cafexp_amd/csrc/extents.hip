@@ -120,7 +120,7 @@ __device__ inline int2 plan_tile_entry(const PlanLaunch& L, const int* s_first, 
         if (hi < lo) { lo = zlo; hi = zlo; }               // an all-zero tile still runs one K tile: the panel must receive its zeros
         hi = min(hi, L.k_valid - 1);
     }
-    return make_int2((op << 24) | tl, ((lo / kBK) << 16) | (hi / kBK - lo / kBK + 1));
+    return make_int2((op << 24) | tl, ((lo / L.kb) << 16) | (hi / L.kb - lo / L.kb + 1));
 }
 
 // The last kPlanTail rounds are dealt as ONE batch, longest tile first, each to the workgroup with the least load at that

@@ -66,13 +66,13 @@ constexpr int a_stride(int bm) { return (bm % 32 == 16) ? bm : bm + 16; }
 // along lane >> 4), so D' = B^T A^T = C^T lands in the accumulators -- lane & 15 is then the ROW of C and (lane >> 4) + 4
 // reg its column, and a store instruction writes four columns x 16 consecutive rows = four full 128-byte lines of the
 // transposed factor, as wide as the row-major store of the other variants (32-byte pieces measured 8 % slower).
-template <int MI, bool MUL, int LEAF, bool TRANS = false>
-__global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI)) void prune_gemm_kernel(const GemmArgs a) {
+template <int KB, int MI, bool MUL, int LEAF, bool TRANS = false>
+__global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI, KB)) void prune_gemm_kernel(const GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the body uses amdgcn-only types (buffer resource); hipcc's host pass only needs the stub
     constexpr int BM = 16 * MI;
     constexpr int SA = a_stride(BM);
     constexpr int kBStride = b_stride(MI);
-    constexpr int A_TILE = kBK * SA, B_TILE = kBK * kBStride, STAGE = A_TILE + B_TILE;
+    constexpr int A_TILE = KB * SA, B_TILE = KB * kBStride, STAGE = A_TILE + B_TILE;
     __shared__ double lds[2 * STAGE];
 
     const int tid = threadIdx.x;
@@ -96,9 +96,9 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI)) void prune_gemm_kern
 
     // per-lane constants that do not depend on the tile (tile origins travel in the scalar offsets)
     constexpr bool A_CONTIG = (SA == BM);
-    constexpr int NS = kBK / 4;                    // k-steps of a K tile = DMA "quarters" of a stage (4 k-rows each, one per wave)
+    constexpr int NS = KB / 4;                    // k-steps of a K tile = DMA "quarters" of a stage (4 k-rows each, one per wave)
     constexpr int SLOTS = 4 * NS;
-    constexpr int NP = kBK * BM / 128, PER = (NP + SLOTS - 1) / SLOTS;     // 1 KB pieces of the contiguous [kBK][BM] A image
+    constexpr int NP = KB * BM / 128, PER = (NP + SLOTS - 1) / SLOTS;     // 1 KB pieces of the contiguous [KB][BM] A image
     unsigned a_voff[NS][PER > 0 ? PER : 1];      // bytes
     int a_dst[NS][PER > 0 ? PER : 1];
     if (A_CONTIG) {
@@ -122,8 +122,8 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI)) void prune_gemm_kern
     const unsigned lane16 = (unsigned)(lane * 16);
     const int a_off = l4 * SA + l15;
     const int b_off = A_TILE + l4 * kBStride + wave * 32 + l15;
-    const int n_k = (a.k_valid + kBK - 1) / kBK;
-    const int last_steps = (a.k_valid - (n_k - 1) * kBK + 3) / 4;
+    const int n_k = (a.k_valid + KB - 1) / KB;
+    const int last_steps = (a.k_valid - (n_k - 1) * KB + 3) / 4;
     auto span_bytes = [](int64_t doubles) -> int { return (int)(doubles * 8 > 0xFFFFFFF0ll ? 0xFFFFFFF0ll : doubles * 8); };
 
     // Tile descriptor (all scalar): the op it belongs to, buffer resources of the A matrix / child panel / parent panel and
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI)) void prune_gemm_kern
     {
         const Tile first = decode(e_cur);
 #pragma unroll
-        for (int q = 0; q < NS; ++q) stage_quarter(first, first.kt0 * kBK, 0, q);
+        for (int q = 0; q < NS; ++q) stage_quarter(first, first.kt0 * KB, 0, q);
     }
     int g = 0;                                              // running K-tile count: stage parity
     __syncthreads();                                        // vmcnt(0) + barrier: the first K tile has landed (later
@@ -233,13 +233,13 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI)) void prune_gemm_kern
             for (int i = 0; i < MI; ++i) af[i] = base[a_off + i * 16];
             read_b(base, 0, bfr[0]);
         }
-        const int nkt = cur.nkt, kbase = cur.kt0 * kBK;     // this tile's K tiles: kbase, kbase + 16, ...
+        const int nkt = cur.nkt, kbase = cur.kt0 * KB;     // this tile's K tiles: kbase, kbase + 16, ...
         const int steps_last = cur.kt0 + nkt == n_k ? last_steps : NS;  // only the matrix's last K tile is ragged
         for (int kt = 0; kt + 1 < nkt; ++kt) {
             const int buf = g & 1;
             const double* base = lds + buf * STAGE;
             const double* nbase = lds + (buf ^ 1) * STAGE;
-            const int k1 = kbase + (kt + 1) * kBK;          // K tile being staged into the other stage
+            const int k1 = kbase + (kt + 1) * KB;          // K tile being staged into the other stage
             const bool next_full = kt + 2 < nkt;            // K tile kt+1 is another pipelined one (not this tile's last)
 #pragma unroll
             for (int s4 = 0; s4 < NS; ++s4) {
@@ -248,8 +248,8 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI)) void prune_gemm_kern
                     stage_quarter(cur, k1, buf ^ 1, s4 + 1);
                 } else {
                     __syncthreads();                        // K tile kt+1 has landed; every wave has read all of K tile kt
-                    if (next_full) stage_quarter(cur, k1 + kBK, buf, 0);
-                    else if (has_next) stage_quarter(nxt, nxt.kt0 * kBK, buf, 0);
+                    if (next_full) stage_quarter(cur, k1 + KB, buf, 0);
+                    else if (has_next) stage_quarter(nxt, nxt.kt0 * KB, buf, 0);
                 }
                 const bool pre = s4 < NS - 1 || next_full;  // uniform
                 const double* src = s4 < NS - 1 ? base : nbase;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI)) void prune_gemm_kern
             const int buf = g & 1;
             const double* base = lds + buf * STAGE;
             if (has_next) {
-                const int nk0 = nxt.kt0 * kBK;
+                const int nk0 = nxt.kt0 * KB;
                 if (nkt == 1) stage_quarter(nxt, nk0, buf ^ 1, 0);
 #pragma unroll
                 for (int q = 1; q < NS; ++q) stage_quarter(nxt, nk0, buf ^ 1, q);
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI)) void prune_gemm_kern
         };
         auto epilogue = [&](auto full) {
             // (a second set of prefetched operands only where the register budget has room: not with four waves per SIMD)
-            constexpr int NB = (LEAF == 3 || prune_gemm_wg_per_cu(MI) >= 4) ? 1 : 2;
+            constexpr int NB = (LEAF == 3 || prune_gemm_wg_per_cu(MI, KB) >= 4) ? 1 : 2;
             Pre pre[NB];
             if (MUL || LEAF) prefetch(0, pre[0], full);
             // full unroll is mandatory: a runtime i would index the accumulator array dynamically and demote
@@ -475,11 +475,11 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI)) void prune_gemm_kern
 // per step of MI.  tiles_by_mi[mi]: tiles of the whole group at that height.  Heights 2 and 3 (32 / 48 rows) exist for the
 // real-data regime (mammals: M = 140, 9 K tiles, a launch is ONE round of tiles and lasts as long as one tile: 18 us at 64
 // rows, of which 8 are the wave's 9 x 32 MFMAs).
-int prune_gemm_pick_mi(int64_t tiles_by_mi[10], int n_cu) {
+int prune_gemm_pick_mi(int64_t tiles_by_mi[10], int n_cu, int kb) {
     int best = 9;
     double best_cost = 1e300;
     for (int mi = 9; mi >= 2; --mi) {
-        const int slots = prune_gemm_wg_per_cu(mi) * n_cu / 8 * 8;
+        const int slots = prune_gemm_wg_per_cu(mi, kb) * n_cu / 8 * 8;
         const int64_t rounds = (tiles_by_mi[mi] + slots - 1) / slots;
         // (32- and 48-row tiles stage a B tile for few rows: only worth it when the launch is one round anyway -- the
         // small-matrix regime, where a tile's latency is the launch's)
@@ -493,8 +493,8 @@ int prune_gemm_pick_mi(int64_t tiles_by_mi[10], int n_cu) {
 // above), a multiple of 8 so that every XCD gets the same number.  XCD x (blocks x, x+8, ...) owns the (category, column
 // tile) pairs x, x+8, ... of every op of the launch and its blocks share those pairs' row tiles: a small launch gets as
 // many blocks per XCD as the busiest XCD (XCD 0) has tiles.
-int prune_gemm_blocks(int64_t tiles_xcd0, int n_cu, int mi) {
-    int blocks = std::min(prune_gemm_wg_per_cu(mi) * n_cu / 8 * 8, 8 * kPlanLanes);     // (the planner deals with one lane per workgroup of an XCD)
+int prune_gemm_blocks(int64_t tiles_xcd0, int n_cu, int mi, int kb) {
+    int blocks = std::min(prune_gemm_wg_per_cu(mi, kb) * n_cu / 8 * 8, 8 * kPlanLanes);     // (the planner deals with one lane per workgroup of an XCD)
     if (tiles_xcd0 * 8 < blocks) blocks = (int)(tiles_xcd0 * 8);
     return blocks < 8 ? 8 : blocks;
 }
@@ -506,26 +506,26 @@ int prune_gemm_blocks(int64_t tiles_xcd0, int n_cu, int mi) {
         if (ev0) hipExtLaunchKernelGGL((__VA_ARGS__), grid, block, 0, stream, ev0, ev1, 0, a);              \
         else hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, stream, a);                               \
     } while (0)
-template <int MI>
+template <int KB, int MI>
 static void launch_mi(const GemmArgs& a, GemmVariant v, dim3 grid, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     const dim3 block(256);
     const int leaf = v.leaf == 1 ? (a.err ? 3 : 1) : v.leaf;
     if (leaf == 2) {                                       // gathered sibling factor: always the launch that creates the panel
-        CAFE_LAUNCH_GEMM(prune_gemm_kernel<MI, false, 2>);
+        CAFE_LAUNCH_GEMM(prune_gemm_kernel<KB, MI, false, 2>);
         return;
     }
     if (v.trans) {                                         // factor GEMM: transposed plain store
-        CAFE_LAUNCH_GEMM(prune_gemm_kernel<MI, false, 0, true>);
+        CAFE_LAUNCH_GEMM(prune_gemm_kernel<KB, MI, false, 0, true>);
         return;
     }
     if (v.mode) {
-        if (leaf == 3) CAFE_LAUNCH_GEMM(prune_gemm_kernel<MI, true, 3>);
-        else if (leaf == 1) CAFE_LAUNCH_GEMM(prune_gemm_kernel<MI, true, 1>);
-        else CAFE_LAUNCH_GEMM(prune_gemm_kernel<MI, true, 0>);
+        if (leaf == 3) CAFE_LAUNCH_GEMM(prune_gemm_kernel<KB, MI, true, 3>);
+        else if (leaf == 1) CAFE_LAUNCH_GEMM(prune_gemm_kernel<KB, MI, true, 1>);
+        else CAFE_LAUNCH_GEMM(prune_gemm_kernel<KB, MI, true, 0>);
     } else {
-        if (leaf == 3) CAFE_LAUNCH_GEMM(prune_gemm_kernel<MI, false, 3>);
-        else if (leaf == 1) CAFE_LAUNCH_GEMM(prune_gemm_kernel<MI, false, 1>);
-        else CAFE_LAUNCH_GEMM(prune_gemm_kernel<MI, false, 0>);
+        if (leaf == 3) CAFE_LAUNCH_GEMM(prune_gemm_kernel<KB, MI, false, 3>);
+        else if (leaf == 1) CAFE_LAUNCH_GEMM(prune_gemm_kernel<KB, MI, false, 1>);
+        else CAFE_LAUNCH_GEMM(prune_gemm_kernel<KB, MI, false, 0>);
     }
 }
 
@@ -535,17 +535,13 @@ hipError_t launch_prune_gemm(const GemmArgs& a, GemmVariant v, int blocks, hipSt
     if (v.trans && (v.leaf || v.mode)) return hipErrorInvalidValue;
     dim3 grid(blocks, 1, 1);
     (void)hipGetLastError();
+    if (a.kb != 8 && a.kb != 16) return hipErrorInvalidValue;
+#define CAFE_MI_CASE(M) case M: if (a.kb == 8) launch_mi<8, M>(a, v, grid, stream, ev0, ev1); else launch_mi<16, M>(a, v, grid, stream, ev0, ev1); break;
     switch (a.mi) {
-        case 2: launch_mi<2>(a, v, grid, stream, ev0, ev1); break;
-        case 3: launch_mi<3>(a, v, grid, stream, ev0, ev1); break;
-        case 4: launch_mi<4>(a, v, grid, stream, ev0, ev1); break;
-        case 5: launch_mi<5>(a, v, grid, stream, ev0, ev1); break;
-        case 6: launch_mi<6>(a, v, grid, stream, ev0, ev1); break;
-        case 7: launch_mi<7>(a, v, grid, stream, ev0, ev1); break;
-        case 8: launch_mi<8>(a, v, grid, stream, ev0, ev1); break;
-        case 9: launch_mi<9>(a, v, grid, stream, ev0, ev1); break;
+        CAFE_MI_CASE(2) CAFE_MI_CASE(3) CAFE_MI_CASE(4) CAFE_MI_CASE(5) CAFE_MI_CASE(6) CAFE_MI_CASE(7) CAFE_MI_CASE(8) CAFE_MI_CASE(9)
         default: return hipErrorInvalidValue;
     }
+#undef CAFE_MI_CASE
     return hipGetLastError();
 }
 

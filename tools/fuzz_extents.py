@@ -37,14 +37,17 @@ for case in range(n_cases):
         os.environ.pop(k, None)
     if rng.integers(0, 3) == 0:
         os.environ["CAFE_FORCE_TILE"] = str(int(rng.choice([2, 3, 4, 6, 7, 8])))
+    os.environ["CAFE_KB"] = str(int(rng.choice([8, 16])))   # depth of K2's K tiles (normally by matrix order)
     fast = capi.Context(pb, max_categories=8)
     os.environ.pop("CAFE_FORCE_TILE", None)
+    os.environ["CAFE_KB"] = "16" if os.environ["CAFE_KB"] == "8" else "8"
     os.environ["CAFE_NO_KSKIP"] = "1"
     if rng.integers(0, 2) == 0:
         os.environ["CAFE_NO_GROUPS"] = "1"                   # ... and one op per launch from the slot pool (the grouped schedule is the default)
     plain = capi.Context(pb, max_categories=8)
     os.environ.pop("CAFE_NO_KSKIP")
     os.environ.pop("CAFE_NO_GROUPS", None)
+    os.environ.pop("CAFE_KB", None)
     ok = True
     for pr, alpha in calls + calls[:1]:
         def run(ctx):
