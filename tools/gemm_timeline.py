@@ -1,6 +1,7 @@
 """Scratch: per-workgroup lifetime and placement of the last K2 launch (CAFE_GEMM_STAMPS=1).
 
-The persistent K2 kernel writes one record per workgroup: HW_ID, XCC_ID, start, epilogue ticks, tiles, end (100 MHz ticks).
+The persistent K2 kernel writes one record per workgroup: HW_ID, XCC_ID, start, epilogue | K-loop ticks, tiles | K tiles, end
+(100 MHz ticks).
 Reports how evenly the workgroups finish (tail of the launch) and whether blockIdx.x & 7 picks the XCD.
 """
 import os, sys, collections
@@ -27,9 +28,8 @@ w = ctx.debug_stamps(6 * nblk).reshape(-1, 6)
 idx = np.nonzero(w[:, 5] > 0)[0]
 w = w[idx]
 hw, xcc, t0, t3 = (w[:, i].astype(np.int64) for i in (0, 1, 2, 5))
-ep, nt = w[:, 3].astype(np.int64), w[:, 4].astype(np.int64) & 0xFFFF
-k01 = w[:, 4].astype(np.int64) >> 16
-print("first two K tiles of an output tile: %.2f us on average; an average K-tile pair over the lifetime: %.2f us" % ((k01 / np.maximum(nt, 1)).mean() / 100.0, 2 * ((w[:, 5].astype(np.int64) - w[:, 2].astype(np.int64)) / np.maximum(nt, 1)).mean() / 100.0 / 46))
+# word 3: epilogue ticks (low 32 bits) | K-loop ticks << 32; word 4: tiles (low 20 bits) | K tiles << 20 (tools/k2_tile_costs.py)
+ep, nt = w[:, 3].astype(np.int64) & 0xFFFFFFFF, w[:, 4].astype(np.int64) & 0xFFFFF
 print("tiles per workgroup: min %d max %d; epilogue us per tile (issue to last store issued): mean %.2f p90 %.2f; share of lifetime %.2f%%"
       % (nt.min(), nt.max(), (ep / np.maximum(nt, 1)).mean() / 100.0, np.percentile(ep / np.maximum(nt, 1), 90) / 100.0, 100.0 * ep.sum() / (t3 - t0).sum()))
 print("workgroups recorded", len(w))

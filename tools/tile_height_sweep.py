@@ -7,7 +7,7 @@ from cafexp_amd.gamma_rates import discrete_gamma
 pb, _ = synth.make_problem(n_families=50000)
 probs, mult = discrete_gamma(8, 2.0)
 pr = P.Params(lambdas=np.array([0.002]), prior=P.prior_uniform(750), multipliers=mult, cat_probs=probs)
-sweeps = ({}, {"CAFE_FORCE_TILE": "4"}, {"CAFE_FORCE_TILE": "5"}, {"CAFE_FORCE_TILE": "7"}, {"CAFE_FORCE_TILE": "9"},
+sweeps = ({}, {"CAFE_FORCE_TILE": "3"}, {"CAFE_FORCE_TILE": "4"}, {"CAFE_FORCE_TILE": "5"}, {"CAFE_FORCE_TILE": "7"}, {"CAFE_FORCE_TILE": "9"}, {"CAFE_KB": "16"},
           {"CAFE_PLAN_FIXED": "2"}, {"CAFE_PLAN_FIXED": "6"}, {})
 if len(sys.argv) > 1 and sys.argv[1] == "bias3":
     sweeps = tuple({"CAFE_PLAN_BIAS3": v} for v in (sys.argv[2:] or ["100,100,100", "89,103,110", "83,105,116", "78,106,124"]))
