@@ -50,7 +50,7 @@ int comm_wait_stream(cafe_ctx* c, hipStream_t s) {
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spin = 0;; ++spin) {
         const hipError_t e = hipStreamQuery(s);
-        if (e == hipSuccess) return CAFE_OK;
+        if (e == hipSuccess) { (void)hipGetLastError(); return CAFE_OK; }      // (the polls left hipErrorNotReady as the thread's last error)
         if (e != hipErrorNotReady) { set_err(c, "hipStreamQuery failed: %s", hipGetErrorString(e)); comm_abort(c); return CAFE_ERR_DEVICE; }
         if ((spin & 63) == 63) {
             ncclResult_t async = ncclSuccess;
