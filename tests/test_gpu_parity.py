@@ -241,19 +241,26 @@ def test_tree_shapes(capi, oracle, newick):
 @pytest.mark.parametrize("M,R", [(50, 30), (70, 75), (100, 110), (135, 140), (150, 128)])
 def test_every_row_tile_height(capi, oracle, M, R):
     """K2's row tile is 16*MI rows, MI = 2..9, chosen per launch; force each in turn over a sweep of M and R so that
-    every instantiation (odd MI: contiguous A image; even MI: padded rows, masked DMA lanes; partial last tiles) runs."""
+    every instantiation (odd MI: contiguous A image; even MI: padded rows, masked DMA lanes; partial last tiles; K tiles 16
+    and 8 deep) runs."""
     rng = np.random.default_rng(M * 1000 + R)
     pb = _random_problem(rng, "(((A:1,B:2):1,C:1.5):0.7,((D:1,E:1):2,(F:0.5,(G:1,H:3):1):1):1);", 150, M, R, min(M - 10, 40))
     probs, mult = oracle.discrete_gamma(2, 1.1)
-    ctx = capi.Context(pb, max_categories=2)
     prs = (P.Params(lambdas=np.array([0.015]), prior=P.prior_uniform(R)),
            P.Params(lambdas=np.array([0.015]), prior=P.prior_uniform(R), multipliers=mult, cat_probs=probs))
     wants = [oracle.score(pb, pr) for pr in prs]
-    for mi in (0, 2, 3, 4, 5, 6, 7, 8, 9):
-        ctx.force_tile(mi)
-        for pr, want in zip(prs, wants):
-            got, res = ctx.score(pr, alpha=1.1, per_family=True)
-            assert rel_err(got, want) <= SCORE_TOL, (M, R, mi, got, want)
+    import os
+    for kb in ("16", "8"):                                   # depth of the K tiles: 16 is what a matrix order < 256 gets, 8 the large ones
+        os.environ["CAFE_KB"] = kb
+        try:
+            ctx = capi.Context(pb, max_categories=2)
+        finally:
+            del os.environ["CAFE_KB"]
+        for mi in (0, 2, 3, 4, 5, 6, 7, 8, 9):
+            ctx.force_tile(mi)
+            for pr, want in zip(prs, wants):
+                got, res = ctx.score(pr, alpha=1.1, per_family=True)
+                assert rel_err(got, want) <= SCORE_TOL, (M, R, kb, mi, got, want)
     pr = prs[1]
     g = ctx.root_likelihoods(3, 1)
     o = oracle.prune(pb, pr, 3, mult=mult[1])
