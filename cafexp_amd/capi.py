@@ -70,7 +70,7 @@ EXPORTS = [
     "cafe_comm_unique_id", "cafe_comm_attach", "cafe_comm_detach", "cafe_shard_plan", "cafe_shard_plan_scaled", "cafe_create_sharded",
     "cafe_sharded_destroy", "cafe_sharded_last_error", "cafe_sharded_score", "cafe_sharded_family_results",
     "cafe_sharded_size", "cafe_sharded_context", "cafe_set_graphs", "cafe_executed_flops", "cafe_get_extents", "cafe_debug_launch_flops", "cafe_debug_launch_ms", "cafe_debug_plan_check",
-    "cafe_debug_fail_next", "cafe_debug_column_extents",
+    "cafe_debug_fail_next", "cafe_debug_column_extents", "cafe_debug_leaf_transposes",
 ]
 CAFE_COMM_ID_BYTES = 128
 
@@ -439,6 +439,14 @@ class Context:
         n = C.c_int64()
         self._check(self._lib.cafe_debug_column_extents(self._h, node, category, _p(out, _i32p), out.size, C.byref(n)))
         return out[:n.value]
+
+    def leaf_transposes(self):
+        """(leaf branches with a transposed copy of their matrix for the assemble passes, whether the last call used them)."""
+        self._lib.cafe_debug_leaf_transposes.restype = C.c_int
+        self._lib.cafe_debug_leaf_transposes.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        n, used = C.c_int32(), C.c_int32()
+        self._check(self._lib.cafe_debug_leaf_transposes(self._h, C.byref(n), C.byref(used)))
+        return n.value, bool(used.value)
 
     def launch_flops(self):
         """Per K2 launch of the last call: (executed flops, flops over all K tiles, tile height in 16-row blocks)."""

@@ -98,6 +98,12 @@ struct cafe_ctx {
     std::vector<cafe::GemmOp> h_gemm_ops;    // static part of the K2 descriptors (n_row_tiles is filled per call)
     std::vector<cafe::GatherArgs> h_gather_ops;
     cafe::GatherArgs* d_gather_ops = nullptr;
+    // transposed copies of the row-major matrices of the leaf branches that meet an interior sibling's factor in an assemble
+    // pass (GatherArgs::lt): [lt_pairs.size()][Kmax][M + 1][factor_ld], filled after K1 by every call without an error model
+    double* d_lt = nullptr;
+    int32_t* d_lt_pairs = nullptr;
+    std::vector<int32_t> lt_pairs;           // pair index in the row-major pool
+    bool lt_used_last = false;
     cafe::GemmOp* h_gemm_stage = nullptr;    // pinned
     cafe::DescSet desc;                      // stream path
     bool panels_dirty = false;               // the last call returned NaN: stale NaNs may sit in padding rows; cleared before the next call

@@ -313,7 +313,7 @@ void free_device(cafe_ctx* c) {
     auto free_desc = [](DescSet& d) { hipFree(d.d_gemm_ops); hipFree(d.d_plan_desc); hipFree(d.d_plan); d = DescSet(); };
     free_desc(c->desc);
     for (auto& g : c->graphs) free_desc(g.second.desc);
-    hipFree(c->d_gather_ops);
+    hipFree(c->d_gather_ops); hipFree(c->d_lt); hipFree(c->d_lt_pairs);
     if (c->h_gemm_stage) hipHostFree(c->h_gemm_stage);
     if (c->h_plan_desc) hipHostFree(c->h_plan_desc);
     if (c->ev_upload) hipEventDestroy(c->ev_upload);
@@ -824,6 +824,31 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     // static descriptors (n_row_tiles of a K2 op follows the tile height, chosen per call)
     c->h_gemm_ops.assign(std::max(1, c->n_gemm_ops), GemmOp{});
     c->h_gather_ops.assign(std::max(1, c->n_gather_ops), GatherArgs{});
+    // Leaf branches whose matrix an assemble pass multiplies with a factor: a transposed copy each (leaf_transpose_kernel), if
+    // the memory is there -- the pass then reads the leaf's column as lines, like the factor's, instead of 8 bytes per row.
+    const int64_t lt_kstride = (int64_t)(c->M + 1) * c->factor_ld;
+    std::vector<int> lt_of_pair(std::max(1, c->n_pairs[0]), -1);
+    if (!std::getenv("CAFE_NO_LEAF_T")) {
+        for (const Op& op : c->ops)
+            if (op.type == 0 && op.n_src >= 1 && op.n_src <= 2 && op.n_leaf >= 1 && op.n_leaf <= 2)
+                for (int l = 0; l < op.n_leaf; ++l) {
+                    const int pr = c->pair_of[op.leaf_node[l]];
+                    if (lt_of_pair[pr] < 0) { lt_of_pair[pr] = (int)c->lt_pairs.size(); c->lt_pairs.push_back(pr); }
+                }
+        const size_t lt_bytes = sizeof(double) * ((size_t)c->lt_pairs.size() * c->Kmax * lt_kstride + 2 * kBN);
+        size_t free_now = 0, total_now = 0;
+        HIP_TRY(c, hipMemGetInfo(&free_now, &total_now));
+        const bool fits = !c->lt_pairs.empty() && (size_t)c->lt_pairs.size() * c->Kmax <= 65535u && lt_bytes <= free_now / 4 &&
+                          (!c->workspace_limit || lt_bytes <= c->workspace_limit / 8);
+        if (fits) {
+            HIP_TRY(c, hipMalloc(&c->d_lt, lt_bytes));
+            HIP_TRY(c, hipMemset(c->d_lt, 0, lt_bytes));
+            HIP_TRY(c, hipMalloc(&c->d_lt_pairs, sizeof(int32_t) * c->lt_pairs.size()));
+            HIP_TRY(c, hipMemcpy(c->d_lt_pairs, c->lt_pairs.data(), sizeof(int32_t) * c->lt_pairs.size(), hipMemcpyHostToDevice));
+        } else {
+            c->lt_pairs.clear();
+        }
+    }
     for (const Op& op : c->ops) {
         const int32_t* cnt_base = c->subtree_dedup ? c->d_leaf_cnt[op.parent] : c->d_counts;
         const int64_t cnt_ld = c->subtree_dedup ? c->pat_cols[op.parent] : c->Fp;
@@ -875,6 +900,12 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
             }
             // (the root's vector is read whole by the reduction and has no extent record)
             g.tileext = c->panel_extents && !op.to_root && !c->no_asm_skip ? c->d_tileext[op.parent] : nullptr;
+            g.lt_kstride = lt_kstride;
+            if (c->d_lt && op.n_src >= 1)
+                for (int l = 0; l < op.n_leaf && l < kMaxLeafPerOp; ++l) {
+                    const int q = lt_of_pair[c->pair_of[op.leaf_node[l]]];
+                    g.lt[l] = q < 0 ? nullptr : c->d_lt + (int64_t)q * c->Kmax * lt_kstride;
+                }
         }
     }
     HIP_TRY(c, hipMalloc(&c->d_gather_ops, sizeof(GatherArgs) * c->h_gather_ops.size()));
@@ -1180,6 +1211,16 @@ int record_call(cafe_ctx* c, DescSet& ds, int K, bool gamma, bool rootmax, bool 
         }
     }
 
+    const bool leaf_t = c->d_lt && !use_err;
+    c->lt_used_last = leaf_t;
+    if (leaf_t) {                            // transposed copies of the leaf matrices that meet a factor in an assemble pass
+        LeafTArgs lt{};
+        lt.pool = c->pool; lt.pairs = c->d_lt_pairs; lt.pool_pairs = c->n_pairs[0]; lt.n_list = (int)c->lt_pairs.size();
+        lt.n_x = c->M + 1; lt.ld_t = c->factor_ld; lt.dst = c->d_lt;
+        lt.kstride = (int64_t)(c->M + 1) * c->factor_ld; lt.pair_stride = lt.kstride * c->Kmax;
+        HIP_TRY(c, launch_leaf_transpose(lt, lt.n_list, K, s));
+    }
+
     // ---- prune, chunk by chunk (one chunk unless the workspace is limited)
     c->gemm_ev_used = 0;
     c->gemm_launches_info.clear();
@@ -1210,6 +1251,7 @@ int record_call(cafe_ctx* c, DescSet& ds, int K, bool gamma, bool rootmax, bool 
                 gg.err = use_err ? c->d_err : nullptr; gg.n_dev = use_err ? c->n_dev : 0;
                 gg.uniform_ld = uniform_ld;
                 gg.f0 = c->subtree_dedup ? 0 : f0;
+                gg.leaf_t = leaf_t ? 1 : 0;
                 HIP_TRY(c, launch_leaf_gather_group(gg, c->h_gather_ops.data() + g.first_desc, s));
                 continue;
             }
@@ -1716,6 +1758,13 @@ int cafe_get_extents(cafe_ctx* ctx, int32_t node, int32_t category, int32_t* mat
         HIP_TRY(ctx, hipMemcpy(panel_ext, ctx->d_tileext[node] + (size_t)category * nt * 2, sizeof(int32_t) * 2 * nt, hipMemcpyDeviceToHost));
         if (n_tiles) *n_tiles = nt;
     }
+    return CAFE_OK;
+}
+
+int cafe_debug_leaf_transposes(cafe_ctx* ctx, int32_t* n_branches, int32_t* used_by_last_call) {
+    if (!ctx) return CAFE_ERR_ARGUMENT;
+    if (n_branches) *n_branches = ctx->d_lt ? (int32_t)ctx->lt_pairs.size() : 0;
+    if (used_by_last_call) *used_by_last_call = ctx->lt_used_last ? 1 : 0;
     return CAFE_OK;
 }
 

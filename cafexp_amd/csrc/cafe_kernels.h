@@ -173,7 +173,26 @@ struct GatherArgs {
     // [category][ld / 128][2] zero extent of each 128-column tile of dst (extents.hip), or nullptr: rows outside it (rounded
     // out to K2's 16-row K tiles) are neither read nor written by the assemble pass
     const int32_t* tileext;
+    // TRANSPOSED copies of the leaf children's row-major matrices (leaf_transpose_kernel), laid out like a factor:
+    // lt[l][category][count x][15 + row s] = P_leaf[s][x], ld_src[0] doubles per count -- so that the assemble pass reads a
+    // leaf's factor as whole lines, like the interior children's, instead of one 8-byte element per matrix row.  nullptr: none
+    // (the pass then gathers from the row-major matrix on its way out).
+    const double* lt[kMaxLeafPerOp];
+    int64_t lt_kstride;             // doubles between the categories of lt[l]
 };
+// One transposed copy per (leaf branch that takes part in an assemble pass, category): src slot of the row-major pool -> dst.
+struct LeafTArgs {
+    MatrixPool pool;                // row-major pool
+    const int32_t* pairs;           // [n_pairs] branch (pair index of the row-major pool); slot = category * pool_pairs + pair
+    int32_t pool_pairs;
+    int32_t n_list;                 // entries of `pairs`
+    int32_t n_x;                    // counts 0..n_x-1 (columns of P read)
+    int32_t ld_t;                   // doubles per count in dst
+    double* dst;                    // [pair][category][n_x][ld_t]
+    int64_t kstride;                // doubles between categories
+    int64_t pair_stride;            // doubles between pairs
+};
+hipError_t launch_leaf_transpose(const LeafTArgs& a, int n_pairs, int n_categories, hipStream_t stream);
 
 // Zero extents of the likelihood panels (extents.hip).  One ExtNode per interior non-root node, static per context.
 constexpr int kMaxExtChildren = 4;
@@ -243,6 +262,7 @@ struct GatherGroup {
     int32_t n_dev;
     int32_t uniform_ld;             // > 0 (several column chunks): columns of every panel in this chunk, overrides GatherArgs::ld
     int64_t f0;                     // first family of the chunk (offset into `counts`)
+    int32_t leaf_t;                 // this call filled the transposed leaf matrices (GatherArgs::lt): no error model, copies made
 };
 // One launch for a group of K3 ops of one variant (same n_leaf, n_src, mode; the error model is the call's): d_ops device
 // array, h_ops the same on the host (grid extents)

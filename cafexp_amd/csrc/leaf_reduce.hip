@@ -207,7 +207,10 @@ static void launch_fast(const GatherGroup& g, int mode, dim3 grid, hipStream_t s
 // traffic, profiles/r01).
 constexpr int kAsmT = 64;                   // tile: 64 columns x 64 rows of the transposed index space
 constexpr int kAsmS = kAsmT + 1;            // LDS row stride (doubles): column-wise reads of a row-major tile without conflicts
-template <int NSRC, int NLEAF, int NDEV, bool MUL>
+// LEAFT: the leaf children come as transposed copies of their matrices (GatherArgs::lt, no error model): they are
+// multiplied in phase A like further factors -- the same products in the same order as the gather of phase B, so the panel
+// has the same bits either way.
+template <int NSRC, int NLEAF, int NDEV, bool MUL, bool LEAFT = false>
 __global__ __launch_bounds__(256) void assemble_t_kernel(const GatherGroup g) {
     __shared__ double tile[kAsmT * kAsmS];
     CAFE_GATHER_OP();
@@ -240,6 +243,16 @@ __global__ __launch_bounds__(256) void assemble_t_kernel(const GatherGroup g) {
                 v.x *= f.x;
                 v.y *= f.y;
             }
+            if (LEAFT) {
+#pragma unroll
+                for (int l = 0; l < NLEAF; ++l) {
+                    const int x = a->counts[(int64_t)a->taxon[l] * a->counts_ld + g.f0 + c0 + c];
+                    const double2 f = *reinterpret_cast<const double2*>(a->lt[l] + (int64_t)cat * a->lt_kstride +
+                                                                        (int64_t)x * a->ld_src[0] + i0 + 2 * seg);
+                    v.x *= f.x;
+                    v.y *= f.y;
+                }
+            }
             tile[c * kAsmS + 2 * seg] = v.x;
             tile[c * kAsmS + 2 * seg + 1] = v.y;
         }
@@ -248,13 +261,14 @@ __global__ __launch_bounds__(256) void assemble_t_kernel(const GatherGroup g) {
     // ---- phase B: wave w writes panel rows (indices) i0 + 16 w .. + 15, lane = column
     const int lane = tid & 63, w = tid >> 6;
     const int f = c0 + lane;
-    constexpr int NL = NLEAF > 0 ? NLEAF : 1;
+    constexpr int NG = LEAFT ? 0 : NLEAF;                   // leaves still to gather on the way out
+    constexpr int NL = NG > 0 ? NG : 1;
     constexpr int half = (NDEV - 1) / 2;
     unsigned o[NL][NDEV];
     double wgt[NL][NDEV];
     const double* P[NL];
 #pragma unroll
-    for (int l = 0; l < NLEAF; ++l) {
+    for (int l = 0; l < NG; ++l) {
         const int x = a->counts[(int64_t)a->taxon[l] * a->counts_ld + g.f0 + f];
 #pragma unroll
         for (int i = 0; i < NDEV; ++i) {
@@ -274,7 +288,7 @@ __global__ __launch_bounds__(256) void assemble_t_kernel(const GatherGroup g) {
         if (r < rows) {
             v = tile[lane * kAsmS + 16 * w + rr];
 #pragma unroll
-            for (int l = 0; l < NLEAF; ++l) {
+            for (int l = 0; l < NG; ++l) {
                 const double* row = P[l] + (int64_t)(r + row_off) * g.pool.ld;
                 if (NDEV == 1) {
                     v *= row[o[l][0]];
@@ -291,16 +305,50 @@ __global__ __launch_bounds__(256) void assemble_t_kernel(const GatherGroup g) {
     }
 }
 
-template <int NSRC, int NLEAF, int NDEV>
+template <int NSRC, int NLEAF, int NDEV, bool LEAFT = false>
 static void launch_asm3(const GatherGroup& g, int mode, dim3 grid, hipStream_t stream) {
-    if (mode) hipLaunchKernelGGL((assemble_t_kernel<NSRC, NLEAF, NDEV, true>), grid, dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL((assemble_t_kernel<NSRC, NLEAF, NDEV, false>), grid, dim3(256), 0, stream, g);
+    if (mode) hipLaunchKernelGGL((assemble_t_kernel<NSRC, NLEAF, NDEV, true, LEAFT>), grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((assemble_t_kernel<NSRC, NLEAF, NDEV, false, LEAFT>), grid, dim3(256), 0, stream, g);
 }
 template <int NSRC>
-static void launch_asm(const GatherGroup& g, int n_leaf, int mode, int ndev, dim3 grid, hipStream_t stream) {
+static void launch_asm(const GatherGroup& g, int n_leaf, int mode, int ndev, bool leaf_t, dim3 grid, hipStream_t stream) {
+    if (leaf_t && ndev == 1 && n_leaf == 1) { launch_asm3<NSRC, 1, 1, true>(g, mode, grid, stream); return; }
+    if (leaf_t && ndev == 1 && n_leaf == 2) { launch_asm3<NSRC, 2, 1, true>(g, mode, grid, stream); return; }
     if (n_leaf == 0) launch_asm3<NSRC, 0, 1>(g, mode, grid, stream);
     else if (n_leaf == 1) { if (ndev == 1) launch_asm3<NSRC, 1, 1>(g, mode, grid, stream); else launch_asm3<NSRC, 1, 3>(g, mode, grid, stream); }
     else { if (ndev == 1) launch_asm3<NSRC, 2, 1>(g, mode, grid, stream); else launch_asm3<NSRC, 2, 3>(g, mode, grid, stream); }
+}
+
+// dst[pair][category][x][15 + s] = P[s][x]: a 64 x 64 tile through LDS, 512-byte rows in, 512-byte rows out.  Entries the
+// kernel does not write (the first 15 of a count's run, those behind the matrix) keep the zeros of cafe_create.
+__global__ __launch_bounds__(256) void leaf_transpose_kernel(const LeafTArgs a) {
+    __shared__ double tile[kAsmT * kAsmS];
+    const int x0 = blockIdx.x * kAsmT, s0 = blockIdx.y * kAsmT;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int pi = blockIdx.z % a.n_list, cat = blockIdx.z / a.n_list;
+    const double* __restrict__ P = a.pool.base + ((int64_t)cat * a.pool_pairs + a.pairs[pi]) * a.pool.stride;
+    double* __restrict__ D = a.dst + (int64_t)pi * a.pair_stride + (int64_t)cat * a.kstride;
+    const int n = a.pool.n;
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+        const int s = s0 + 16 * w + rr, x = x0 + lane;
+        tile[(16 * w + rr) * kAsmS + lane] = (s < n && x < a.n_x) ? P[(int64_t)s * a.pool.ld + x] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+        const int x = x0 + 16 * w + rr, s = s0 + lane;
+        if (x < a.n_x && s < n) D[(int64_t)x * a.ld_t + 15 + s] = tile[lane * kAsmS + 16 * w + rr];
+    }
+}
+
+hipError_t launch_leaf_transpose(const LeafTArgs& a, int n_pairs, int n_categories, hipStream_t stream) {
+    if (n_pairs <= 0) return hipSuccess;
+    (void)hipGetLastError();
+    if ((unsigned)(n_pairs * n_categories) > 65535u || a.n_list != n_pairs) return hipErrorInvalidValue;
+    dim3 grid((a.n_x + kAsmT - 1) / kAsmT, (a.pool.n + kAsmT - 1) / kAsmT, n_pairs * n_categories);
+    hipLaunchKernelGGL(leaf_transpose_kernel, grid, dim3(256), 0, stream, a);
+    return hipGetLastError();
 }
 
 // h_ops: the group's descriptors on the host (grid extents and the variant: every op of a group has the same n_leaf, n_src
@@ -322,8 +370,11 @@ hipError_t launch_leaf_gather_group(const GatherGroup& g, const GatherArgs* h_op
     const int ndev = g.err == nullptr ? 1 : g.n_dev;
     if ((ndev == 1 || ndev == 3) && n_leaf <= 2 && n_src >= 1 && n_src <= 2) {
         dim3 grid(max_ld / kAsmT, (max_rows_store + 15 + max_row_off + kAsmT - 1) / kAsmT, z);
-        if (n_src == 1) launch_asm<1>(g, n_leaf, mode, ndev, grid, stream);
-        else launch_asm<2>(g, n_leaf, mode, ndev, grid, stream);
+        bool leaf_t = n_leaf > 0 && g.leaf_t;              // every leaf of every op has its transposed copy, and this call filled them
+        for (int i = 0; i < g.n_ops && leaf_t; ++i)
+            for (int l = 0; l < n_leaf; ++l) leaf_t = leaf_t && h_ops[i].lt[l] != nullptr;
+        if (n_src == 1) launch_asm<1>(g, n_leaf, mode, ndev, leaf_t, grid, stream);
+        else launch_asm<2>(g, n_leaf, mode, ndev, leaf_t, grid, stream);
         return hipGetLastError();
     }
     if ((ndev == 1 || ndev == 3) && n_leaf <= 2 && n_src == 0) {

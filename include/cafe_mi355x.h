@@ -251,6 +251,10 @@ int cafe_get_extents(cafe_ctx* ctx, int32_t node, int32_t category, int32_t* mat
 /* diagnostic: the per-COLUMN zero extents of an interior non-root node's panel in the last call, out[columns][2] (rows outside
  * [lo, hi] of a column are exactly zero; lo > hi: the whole column); *n_cols receives the panel's (padded) column count */
 int cafe_debug_column_extents(cafe_ctx* ctx, int32_t node, int32_t category, int32_t* out, size_t out_len, int64_t* n_cols);
+/* diagnostic: leaf branches whose matrix the context keeps a transposed copy of (leaf_reduce.hip, leaf_transpose_kernel: a
+ * leaf that meets an interior sibling's factor in an assemble pass), and whether the last call used the copies (it does not
+ * when it carries an error model) */
+int cafe_debug_leaf_transposes(cafe_ctx* ctx, int32_t* n_branches, int32_t* used_by_last_call);
 int cafe_get_stats(const cafe_ctx* ctx, cafe_stats* stats);
 /* Flops the K2 launches of the last call executed: a (row tile, column tile) pair runs only the K tiles inside the
  * intersection of the matrix's non-zero extent (K1) and the panel's (extents.hip) -- the products it leaves out all have an

@@ -727,6 +727,44 @@ def test_assemble_pass_skips_rows_outside_the_extent_without_changing_a_bit(capi
 
 
 @pytest.mark.gpu
+def test_assemble_pass_reads_its_leaf_from_a_transposed_copy_without_changing_a_bit(capi, oracle, monkeypatch):
+    """A leaf that meets an interior sibling's factor in an assemble pass is read from a transposed copy of its matrix
+    (leaf_transpose_kernel, made after K1 by every call without an error model) -- whole lines like the factor's instead of
+    8 bytes per matrix row.  Same products in the same order: call for call the bits of a context that gathers from the
+    row-major matrix (CAFE_NO_LEAF_T).  A context with an error model gathers (the three taps are folded on the way out)
+    except in its root-maximum calls (p-value path: no error model there)."""
+    probs, mult = oracle.discrete_gamma(3, 0.9)
+    for n_dev in (0, 3):
+        pb, _ = synth.make_problem(n_taxa=16, n_families=1500, max_count=250, lam_sim=0.003, seed=11, root_cap=120, n_deviations=n_dev)
+        assert pb.matrix_size >= 256
+        prior = P.prior_uniform(pb.max_root_family_size)
+        em = P.error_model_table(P.default_error_model(pb.max_family_size)[:1] + [[0.05, 0.9, 0.05]], pb.max_family_size) if n_dev else None
+        prs = [(P.Params(lambdas=np.array([0.006]), prior=prior, multipliers=mult, cat_probs=probs, error_model=em), 0.9),
+               (P.Params(lambdas=np.array([0.0004]), prior=prior, error_model=em), 1.0),
+               (P.Params(lambdas=np.array([0.0015]), prior=prior, multipliers=mult, cat_probs=probs, error_model=em), 0.9)]
+        monkeypatch.delenv("CAFE_NO_LEAF_T", raising=False)
+        ctx = capi.Context(pb, max_categories=3)
+        n_branches, _ = ctx.leaf_transposes()
+        assert n_branches > 0 and ctx.stats()["n_assemble_passes"] > 0
+        got = []
+        for pr, alpha in prs:
+            got.append(ctx.score(pr, alpha=alpha, per_family=True))
+            assert ctx.leaf_transposes()[1] == (n_dev == 0)
+            assert rel_err(got[-1][0], oracle.score(pb, pr)) <= SCORE_TOL
+        rm = ctx.root_max([0.002])
+        assert ctx.leaf_transposes()[1]
+        monkeypatch.setenv("CAFE_NO_LEAF_T", "1")
+        plain = capi.Context(pb, max_categories=3)
+        assert plain.leaf_transposes() == (0, False)
+        for (pr, alpha), (v, r) in zip(prs, got):
+            v2, r2 = plain.score(pr, alpha=alpha, per_family=True)
+            assert v == v2
+            for key in r:
+                assert np.array_equal(r[key], r2[key]), key
+        assert np.array_equal(rm, plain.root_max([0.002]))
+
+
+@pytest.mark.gpu
 def test_planned_tile_lists_cover_every_tile_once_and_change_no_bit(capi, oracle, monkeypatch):
     """The tiles of a K2 launch -- the tiles of every op of its group -- are dealt to the workgroups by a planner kernel
     (extents.hip, tile_plan_kernel: per round, longest tile to least-loaded workgroup).  The lists read back from the device

@@ -44,9 +44,12 @@ for case in range(n_cases):
     os.environ["CAFE_NO_KSKIP"] = "1"
     if rng.integers(0, 2) == 0:
         os.environ["CAFE_NO_GROUPS"] = "1"                   # ... and one op per launch from the slot pool (the grouped schedule is the default)
+    if rng.integers(0, 2) == 0:
+        os.environ["CAFE_NO_LEAF_T"] = "1"                   # ... and assemble passes that gather their leaf from the row-major matrix
     plain = capi.Context(pb, max_categories=8)
     os.environ.pop("CAFE_NO_KSKIP")
     os.environ.pop("CAFE_NO_GROUPS", None)
+    os.environ.pop("CAFE_NO_LEAF_T", None)
     os.environ.pop("CAFE_KB", None)
     ok = True
     for pr, alpha in calls + calls[:1]:
