@@ -35,6 +35,7 @@ struct Op {
     int gath_panel;
     int step;                   // ops of one step are mutually independent (see Group)
     int desc;                   // index of the op's descriptor in the context's GemmOp / GatherArgs array
+    bool leaf_t = false;        // assemble: every leaf child has a transposed copy of its matrix (GatherArgs::lt)
 };
 
 // A likelihood panel (or the transposed factor panel of a de-duplicated child): where it lives in the arena d_panels

@@ -791,12 +791,47 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
         int a = 100, b = 100, d = 100;
         if (std::sscanf(e, "%d,%d,%d", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0) { c->plan_bias3[0] = a; c->plan_bias3[1] = b; c->plan_bias3[2] = d; }
     }
+    // Leaf branches whose matrix an assemble pass multiplies with a factor get a transposed copy (leaf_transpose_kernel, every
+    // call): the pass then reads the leaf's column as lines, like the factor's, instead of 8 bytes per matrix row (4.0 -> 6 TB/s).
+    // A copy costs 16 N^2 bytes per category and call whatever the number of columns, so a branch gets one only when the
+    // passes that read it write enough columns: >= lt_min N.  Bench table: 31 branches, 139.5 -> 137.9 ms per call; its 1/8
+    // shards copy 2 to 6 branches and take what they took (20.1 / 20.2 ms; with all 30 copied: +0.3 to +0.6 ms).
+    std::vector<int> lt_of_pair(std::max(1, c->n_pairs[0]), -1);
+    if (!std::getenv("CAFE_NO_LEAF_T")) {
+        double lt_min = 6.0;
+        if (const char* e = std::getenv("CAFE_LEAF_T_MIN")) lt_min = atof(e);
+        std::vector<int64_t> served(lt_of_pair.size(), 0);
+        auto eligible = [](const Op& op) { return op.type == 0 && op.n_src >= 1 && op.n_src <= 2 && op.n_leaf >= 1 && op.n_leaf <= 2; };
+        for (const Op& op : c->ops)
+            if (eligible(op))
+                for (int l = 0; l < op.n_leaf; ++l) served[c->pair_of[op.leaf_node[l]]] += cols_of(op.parent) * std::max<int64_t>(1, c->stats.n_chunks);
+        for (size_t pr = 0; pr < served.size(); ++pr)
+            if (served[pr] > 0 && (double)served[pr] >= lt_min * c->N) { lt_of_pair[pr] = (int)c->lt_pairs.size(); c->lt_pairs.push_back((int)pr); }
+        const size_t lt_bytes = sizeof(double) * ((size_t)c->lt_pairs.size() * c->Kmax * (size_t)(c->M + 1) * c->factor_ld + 2 * kBN);
+        size_t free_now = 0, total_now = 0;
+        HIP_TRY(c, hipMemGetInfo(&free_now, &total_now));
+        const bool fits = !c->lt_pairs.empty() && (size_t)c->lt_pairs.size() * c->Kmax <= 65535u && lt_bytes <= free_now / 4 &&
+                          (!c->workspace_limit || lt_bytes <= c->workspace_limit / 8);
+        if (fits) {
+            HIP_TRY(c, hipMalloc(&c->d_lt, lt_bytes));
+            HIP_TRY(c, hipMemset(c->d_lt, 0, lt_bytes));
+            HIP_TRY(c, hipMalloc(&c->d_lt_pairs, sizeof(int32_t) * c->lt_pairs.size()));
+            HIP_TRY(c, hipMemcpy(c->d_lt_pairs, c->lt_pairs.data(), sizeof(int32_t) * c->lt_pairs.size(), hipMemcpyHostToDevice));
+            for (Op& op : c->ops) {
+                if (!eligible(op)) continue;
+                op.leaf_t = true;
+                for (int l = 0; l < op.n_leaf; ++l) op.leaf_t = op.leaf_t && lt_of_pair[c->pair_of[op.leaf_node[l]]] >= 0;
+            }
+        } else {
+            c->lt_pairs.clear();
+        }
+    }
     {
         std::vector<size_t> idx(c->ops.size());
         for (size_t i = 0; i < idx.size(); ++i) idx[i] = i;
         auto key = [&](const Op& o) -> int {                 // launch order inside a step: factor GEMMs, the other GEMMs, then K3
             if (o.type == 1) return o.to_factor ? 0 : 1 + (o.has_gath ? 2 : (o.n_leaf ? 1 : 0)) * 2 + o.mode;
-            return 16 + o.n_src * 32 + o.n_leaf * 2 + o.mode;
+            return 16 + o.n_src * 32 + o.n_leaf * 2 + o.mode + (o.leaf_t ? 1024 : 0);
         };
         std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) {
             const Op &a = c->ops[x], &b = c->ops[y];
@@ -824,31 +859,7 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
     // static descriptors (n_row_tiles of a K2 op follows the tile height, chosen per call)
     c->h_gemm_ops.assign(std::max(1, c->n_gemm_ops), GemmOp{});
     c->h_gather_ops.assign(std::max(1, c->n_gather_ops), GatherArgs{});
-    // Leaf branches whose matrix an assemble pass multiplies with a factor: a transposed copy each (leaf_transpose_kernel), if
-    // the memory is there -- the pass then reads the leaf's column as lines, like the factor's, instead of 8 bytes per row.
     const int64_t lt_kstride = (int64_t)(c->M + 1) * c->factor_ld;
-    std::vector<int> lt_of_pair(std::max(1, c->n_pairs[0]), -1);
-    if (!std::getenv("CAFE_NO_LEAF_T")) {
-        for (const Op& op : c->ops)
-            if (op.type == 0 && op.n_src >= 1 && op.n_src <= 2 && op.n_leaf >= 1 && op.n_leaf <= 2)
-                for (int l = 0; l < op.n_leaf; ++l) {
-                    const int pr = c->pair_of[op.leaf_node[l]];
-                    if (lt_of_pair[pr] < 0) { lt_of_pair[pr] = (int)c->lt_pairs.size(); c->lt_pairs.push_back(pr); }
-                }
-        const size_t lt_bytes = sizeof(double) * ((size_t)c->lt_pairs.size() * c->Kmax * lt_kstride + 2 * kBN);
-        size_t free_now = 0, total_now = 0;
-        HIP_TRY(c, hipMemGetInfo(&free_now, &total_now));
-        const bool fits = !c->lt_pairs.empty() && (size_t)c->lt_pairs.size() * c->Kmax <= 65535u && lt_bytes <= free_now / 4 &&
-                          (!c->workspace_limit || lt_bytes <= c->workspace_limit / 8);
-        if (fits) {
-            HIP_TRY(c, hipMalloc(&c->d_lt, lt_bytes));
-            HIP_TRY(c, hipMemset(c->d_lt, 0, lt_bytes));
-            HIP_TRY(c, hipMalloc(&c->d_lt_pairs, sizeof(int32_t) * c->lt_pairs.size()));
-            HIP_TRY(c, hipMemcpy(c->d_lt_pairs, c->lt_pairs.data(), sizeof(int32_t) * c->lt_pairs.size(), hipMemcpyHostToDevice));
-        } else {
-            c->lt_pairs.clear();
-        }
-    }
     for (const Op& op : c->ops) {
         const int32_t* cnt_base = c->subtree_dedup ? c->d_leaf_cnt[op.parent] : c->d_counts;
         const int64_t cnt_ld = c->subtree_dedup ? c->pat_cols[op.parent] : c->Fp;
@@ -901,11 +912,9 @@ int create_impl(cafe_ctx* c, const cafe_problem* p) {
             // (the root's vector is read whole by the reduction and has no extent record)
             g.tileext = c->panel_extents && !op.to_root && !c->no_asm_skip ? c->d_tileext[op.parent] : nullptr;
             g.lt_kstride = lt_kstride;
-            if (c->d_lt && op.n_src >= 1)
-                for (int l = 0; l < op.n_leaf && l < kMaxLeafPerOp; ++l) {
-                    const int q = lt_of_pair[c->pair_of[op.leaf_node[l]]];
-                    g.lt[l] = q < 0 ? nullptr : c->d_lt + (int64_t)q * c->Kmax * lt_kstride;
-                }
+            if (op.leaf_t)
+                for (int l = 0; l < op.n_leaf && l < kMaxLeafPerOp; ++l)
+                    g.lt[l] = c->d_lt + (int64_t)lt_of_pair[c->pair_of[op.leaf_node[l]]] * c->Kmax * lt_kstride;
         }
     }
     HIP_TRY(c, hipMalloc(&c->d_gather_ops, sizeof(GatherArgs) * c->h_gather_ops.size()));

@@ -329,16 +329,22 @@ __global__ __launch_bounds__(256) void leaf_transpose_kernel(const LeafTArgs a) 
     const double* __restrict__ P = a.pool.base + ((int64_t)cat * a.pool_pairs + a.pairs[pi]) * a.pool.stride;
     double* __restrict__ D = a.dst + (int64_t)pi * a.pair_stride + (int64_t)cat * a.kstride;
     const int n = a.pool.n;
-#pragma unroll 4
+    // (all 16 loads of a thread in flight before the first LDS store, all 16 LDS reads before the first global store)
+    double v[16];
+#pragma unroll
     for (int rr = 0; rr < 16; ++rr) {
         const int s = s0 + 16 * w + rr, x = x0 + lane;
-        tile[(16 * w + rr) * kAsmS + lane] = (s < n && x < a.n_x) ? P[(int64_t)s * a.pool.ld + x] : 0.0;
+        v[rr] = (s < n && x < a.n_x) ? P[(int64_t)s * a.pool.ld + x] : 0.0;
     }
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) tile[(16 * w + rr) * kAsmS + lane] = v[rr];
     __syncthreads();
-#pragma unroll 4
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) v[rr] = tile[lane * kAsmS + 16 * w + rr];
+#pragma unroll
     for (int rr = 0; rr < 16; ++rr) {
         const int x = x0 + 16 * w + rr, s = s0 + lane;
-        if (x < a.n_x && s < n) D[(int64_t)x * a.ld_t + 15 + s] = tile[lane * kAsmS + 16 * w + rr];
+        if (x < a.n_x && s < n) D[(int64_t)x * a.ld_t + 15 + s] = v[rr];
     }
 }
 

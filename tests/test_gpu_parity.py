@@ -743,6 +743,7 @@ def test_assemble_pass_reads_its_leaf_from_a_transposed_copy_without_changing_a_
                (P.Params(lambdas=np.array([0.0004]), prior=prior, error_model=em), 1.0),
                (P.Params(lambdas=np.array([0.0015]), prior=prior, multipliers=mult, cat_probs=probs, error_model=em), 0.9)]
         monkeypatch.delenv("CAFE_NO_LEAF_T", raising=False)
+        monkeypatch.setenv("CAFE_LEAF_T_MIN", "0")           # (a branch gets its copy only when enough columns read it: 6 N by default)
         ctx = capi.Context(pb, max_categories=3)
         n_branches, _ = ctx.leaf_transposes()
         assert n_branches > 0 and ctx.stats()["n_assemble_passes"] > 0

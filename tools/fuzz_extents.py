@@ -38,8 +38,10 @@ for case in range(n_cases):
     if rng.integers(0, 3) == 0:
         os.environ["CAFE_FORCE_TILE"] = str(int(rng.choice([2, 3, 4, 6, 7, 8])))
     os.environ["CAFE_KB"] = str(int(rng.choice([8, 16])))   # depth of K2's K tiles (normally by matrix order)
+    os.environ["CAFE_LEAF_T_MIN"] = str(int(rng.choice([0, 0, 6])))   # transposed leaf matrices for the assemble passes: every eligible branch / the default rule
     fast = capi.Context(pb, max_categories=8)
     os.environ.pop("CAFE_FORCE_TILE", None)
+    os.environ.pop("CAFE_LEAF_T_MIN", None)
     os.environ["CAFE_KB"] = "16" if os.environ["CAFE_KB"] == "8" else "8"
     os.environ["CAFE_NO_KSKIP"] = "1"
     if rng.integers(0, 2) == 0:
