@@ -19,7 +19,9 @@
 // k-major ones K1 already builds for K2 (Pt[j][i-1] = P[i][j]), read through the scalar unit.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <limits>
+#include <memory>
 #include <vector>
 
 #include "cafe_ctx.h"
@@ -31,22 +33,31 @@ namespace {
 constexpr int kTI = 16;                 // parent sizes per wave in K5
 constexpr int kRowsPerBlock = 4 * kTI;
 
-// B_dst[j][f] (op)= (j >= 1) ? P[j][x_f] : 0 for j = 0..M; one thread per family, 8 rows per block row
+// Row groups of a product panel: group 0 = rows 0..16, group g >= 1 = rows 16g+1 .. 16g+16 (what one K5 wave writes).  Whoever
+// writes a panel -- the store of the first child, the multiplies of the others -- records per (64-family tile, row group)
+// whether any value it wrote is non-zero; after the last child the flags describe the finished panel, and the K5 that reads it
+// walks only from the first to the last flagged group: every product it leaves out has an exact zero in it, and
+// max(acc, 0) = acc (all terms are >= 0), so the result has the same bits.
+__device__ inline int group_first_row(int g) { return g == 0 ? 0 : 16 * g + 1; }
+
+// B_dst[j][f] (op)= (j >= 1) ? P[j][x_f] : 0 for j = 0..M; one thread per family, one row group per block row
 template <bool MUL>
 __global__ __launch_bounds__(256) void recon_leaf_kernel(const double* __restrict__ P, int ldp, const int32_t* __restrict__ counts,
-                                                         double* __restrict__ dst, int64_t ld, int M) {
+                                                         double* __restrict__ dst, int64_t ld, int M, int32_t* __restrict__ flags, int n_groups) {
     const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (f >= ld) return;
+    if (f >= ld) return;                                         // (ld is a multiple of 128: whole waves)
     const int x = counts[f];
-    const int j0 = blockIdx.y * 8;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int j = j0 + r;
-        if (j > M) break;
-        const double v = j >= 1 ? P[(int64_t)j * ldp + x] : 0.0;
+    const int g = blockIdx.y, j0 = group_first_row(g), j1 = min(M, 16 * g + 16);
+    bool nz = false;
+    for (int j = j0; j <= j1; ++j) {
+        double v = j >= 1 ? P[(int64_t)j * ldp + x] : 0.0;
         double* o = dst + (int64_t)j * ld + f;
-        *o = MUL ? *o * v : v;
+        if (MUL) v *= *o;
+        *o = v;
+        nz = nz || v != 0.0;
     }
+    const bool any = __any(nz);
+    if ((threadIdx.x & 63) == 0) flags[(f >> 6) * n_groups + g] = any ? 1 : 0;
 }
 
 // v_max_f64 without the canonicalising self-max the compiler adds in front of llvm.maxnum on a loop-carried value
@@ -66,9 +77,11 @@ __device__ inline double vmax(double a, double b) {
 // ext (or nullptr): K1's non-zero extents of this matrix -- per block of 16 parent sizes the first / last child size j with a
 // non-zero entry.  A wave's 16 parent sizes are exactly one such block, so its j loop runs over that range only: every
 // product left out is b * 0 = 0, and max(acc, 0) = acc (acc starts at 0, all terms are >= 0): the same bits.
+// bflags: the row-group flags of B (see above); dflags: those of dst, written here.
 template <bool MUL>
 __global__ __launch_bounds__(256) void maxprod_kernel(const double* __restrict__ Pt, int ldp, const double* __restrict__ B,
-                                                      double* __restrict__ dst, int64_t ld, int M, int kc_rows, const int32_t* __restrict__ ext) {
+                                                      double* __restrict__ dst, int64_t ld, int M, int kc_rows, const int32_t* __restrict__ ext,
+                                                      const int32_t* __restrict__ bflags, int32_t* __restrict__ dflags, int n_groups) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // XCD-aware order: workgroups b, b+8, ... share an XCD; consecutive ones there take the row groups of ONE
@@ -87,9 +100,18 @@ __global__ __launch_bounds__(256) void maxprod_kernel(const double* __restrict__
     const double* pp = Pt + i0;
     int groups = (M + 4) / 4;                                    // rows 0 .. 4*groups-1 cover 0..M
     int g0 = 0;
-    if (ext) {
-        const int lo = ext[2 * (i0 / kTI)], hi = ext[2 * (i0 / kTI) + 1];
-        if (hi < lo) { g0 = 0; groups = 0; }                     // an all-zero block of the matrix: acc stays 0
+    {
+        int lo = 0, hi = M;
+        if (ext) { lo = ext[2 * (i0 / kTI)]; hi = ext[2 * (i0 / kTI) + 1]; }     // hi < lo: an all-zero block of the matrix, acc stays 0
+        if (bflags) {                                            // ... and the rows of B's tile between its first and last flagged group
+            const unsigned long long m = __ballot(lane < n_groups && bflags[(int64_t)ct * n_groups + lane] != 0);     // n_groups <= 64
+            if (m == 0) { lo = 1; hi = 0; }
+            else {
+                lo = max(lo, group_first_row(__builtin_ctzll(m)));
+                hi = min(hi, 16 * (63 - __builtin_clzll(m)) + 16);
+            }
+        }
+        if (hi < lo) { g0 = 0; groups = 0; }
         else { g0 = __builtin_amdgcn_readfirstlane(lo / 4); groups = __builtin_amdgcn_readfirstlane(min(groups, hi / 4 + 1)); }
     }
     double bn[4];
@@ -122,18 +144,25 @@ __global__ __launch_bounds__(256) void maxprod_kernel(const double* __restrict__
             for (int t = 0; t < kTI; ++t) acc[t] = vmax(acc[t], b[u] * pc[t]);
         }
     }
+    bool nz = false;
 #pragma unroll
     for (int t = 0; t < kTI; ++t) {
         const int i = i0 + 1 + t;
         if (i <= M) {
             double* o = dst + (int64_t)i * ld + f;
-            *o = MUL ? *o * acc[t] : acc[t];
+            const double v = MUL ? *o * acc[t] : acc[t];
+            *o = v;
+            nz = nz || v != 0.0;
         }
     }
     if (i0 == 0) {
         double* o = dst + f;
-        *o = MUL ? *o * bp[0] : bp[0];
+        const double v = MUL ? *o * bp[0] : bp[0];
+        *o = v;
+        nz = nz || v != 0.0;
     }
+    const bool any = __any(nz);
+    if (lane == 0) dflags[(int64_t)ct * n_groups + i0 / kTI] = any ? 1 : 0;
 }
 
 // root: C[0] = first arg max over j = 1..jmax of B[j] * prior(j), scanning from max_val = -1
@@ -153,15 +182,22 @@ __global__ __launch_bounds__(256) void root_select_kernel(const double* __restri
 // interior node: state = first arg max_j B[j] * P[i][j], i = the parent's state; P[i][j] = Pt[j][i-1], row 0 = e_0.
 // 64 families per block; the j range is cut into four consecutive segments scanned by four threads per family and
 // combined in segment order with the same strict comparison, which keeps the reference's "first maximum".
+// ext (or nullptr): K1's extents of the matrix -- row i is exactly zero outside [lo, hi] of its block of 16 parent sizes, so
+// the scan covers that range only: outside it every value is 0, which the reference's scan takes at j = 0 (0 > -1) and never
+// again (0 > 0 is false) -- hence the start (0, j = 0) when the range begins behind j = 0.
 __global__ __launch_bounds__(256) void backtrack_kernel(const double* __restrict__ Pt, int ldp, const double* __restrict__ B, int64_t ld,
-                                                        int M, const int32_t* __restrict__ parent_state, int32_t* __restrict__ state) {
+                                                        int M, const int32_t* __restrict__ parent_state, int32_t* __restrict__ state,
+                                                        const int32_t* __restrict__ ext) {
     __shared__ double s_best[4][64];
     __shared__ int s_arg[4][64];
     const int fl = threadIdx.x & 63, seg = threadIdx.x >> 6;
     const int64_t f = (int64_t)blockIdx.x * 64 + fl;          // ld is a multiple of 128: always in range
     const int i = parent_state[f];
-    const int per = (M + 4) / 4;                               // ceil((M + 1) / 4)
-    const int j0 = seg * per, j1 = min(M + 1, j0 + per);
+    int lo = 0, hi = M;
+    if (i == 0) hi = 0;                                        // row 0 = e_0
+    else if (ext) { lo = ext[2 * ((i - 1) >> 4)]; hi = min(M, ext[2 * ((i - 1) >> 4) + 1]); }
+    const int per = (max(0, hi - lo + 1) + 3) / 4;
+    const int j0 = lo + seg * per, j1 = min(hi + 1, j0 + per);
     double best = -1.0;
     int arg = 0;
     for (int j = j0; j < j1; ++j) {
@@ -173,11 +209,22 @@ __global__ __launch_bounds__(256) void backtrack_kernel(const double* __restrict
     s_arg[seg][fl] = arg;
     __syncthreads();
     if (seg == 0) {
+        best = lo > 0 ? 0.0 : -1.0;
+        arg = 0;
 #pragma unroll
-        for (int s2 = 1; s2 < 4; ++s2)
+        for (int s2 = 0; s2 < 4; ++s2)
             if (s_best[s2][fl] > best) { best = s_best[s2][fl]; arg = s_arg[s2][fl]; }
         state[f] = arg;
     }
+}
+
+// out[f][v] = state[v][f]: the host wants a family's nodes side by side
+__global__ __launch_bounds__(256) void state_transpose_kernel(const int32_t* __restrict__ state, int n, int64_t cols, int64_t ld, int32_t* __restrict__ out) {
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= ld) return;
+    const int v0 = blockIdx.y * 16;
+#pragma unroll 4
+    for (int v = v0; v < min(n, v0 + 16); ++v) out[f * n + v] = state[(int64_t)v * cols + f];
 }
 
 // compute_viterbi_sum: one thread per (family, node); NaN = "invalid" (root, or parent size == child size)
@@ -250,20 +297,28 @@ int reconstruct_impl(cafe_ctx* c, const cafe_params* pr, const float* root_prior
     // workspace: one product panel per interior node + the state table, sized to the free memory
     size_t free_b = 0, total_b = 0;
     HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
-    const size_t per_col = (size_t)nI * rows * sizeof(double) + (size_t)n * sizeof(int32_t);
+    // (panels, the state table both ways round, the row-group flags: one int per 64 columns and 16 rows)
+    const size_t per_col = (size_t)nI * rows * sizeof(double) + (size_t)2 * n * sizeof(int32_t) + (size_t)nI * ((M + 15) / 16) * sizeof(int32_t) / 64 + 1;
     const size_t budget = c->workspace_limit ? c->workspace_limit : (size_t)(free_b * 0.8);
     int64_t cols = std::min<int64_t>(c->Fp, (int64_t)(budget / per_col) / kBN * kBN);
     if (cols < kBN) { set_err(c, "cafe_reconstruct: not enough device memory for %d product panels", nI); return CAFE_ERR_MEMORY; }
-    DevBuf panels, st, prior;
-    if (hipMalloc(&panels.p, (size_t)nI * rows * cols * sizeof(double)) != hipSuccess || hipMalloc(&st.p, (size_t)n * cols * sizeof(int32_t)) != hipSuccess ||
-        hipMalloc(&prior.p, sizeof(double) * (jmax + 1)) != hipSuccess) {
+    const int n_groups = (M + 15) / 16;                     // row groups of a panel (flags, see recon_leaf_kernel)
+    const int64_t n_tiles = cols / 64;
+    DevBuf panels, st, prior, flg;
+    if (hipMalloc(&panels.p, (size_t)nI * rows * cols * sizeof(double)) != hipSuccess || hipMalloc(&st.p, (size_t)2 * n * cols * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc(&prior.p, sizeof(double) * (jmax + 1)) != hipSuccess || hipMalloc(&flg.p, sizeof(int32_t) * (size_t)nI * n_tiles * n_groups) != hipSuccess) {
         (void)hipGetLastError();
         set_err(c, "cafe_reconstruct: cannot allocate the workspace (%lld columns)", (long long)cols);
         return CAFE_ERR_MEMORY;
     }
-    HIP_TRY(c, hipMemsetAsync(panels.p, 0, (size_t)nI * rows * cols * sizeof(double), s));     // the padding rows must not hold NaN patterns
     double* d_B = static_cast<double*>(panels.p);
     int32_t* d_state = static_cast<int32_t*>(st.p);
+    int32_t* d_state_t = d_state + (size_t)n * cols;         // [column][node] for the way back
+    int32_t* d_flags = static_cast<int32_t*>(flg.p);
+    const bool use_flags = n_groups <= 64 && !std::getenv("CAFE_NO_RECON_FLAGS");
+    // rows 0..M of a panel are written by its first child; the padding rows (K5 reads in groups of four) must not hold NaN patterns
+    if (rows > M + 1)
+        HIP_TRY(c, hipMemset2DAsync(d_B + (int64_t)(M + 1) * cols, sizeof(double) * (size_t)rows * cols, 0, sizeof(double) * (size_t)(rows - M - 1) * cols, nI, s));
     {
         std::vector<double> hp(jmax + 1);
         for (int j = 0; j <= jmax; ++j) hp[j] = (double)root_prior[j];         // compute() returns a float
@@ -271,7 +326,7 @@ int reconstruct_impl(cafe_ctx* c, const cafe_params* pr, const float* root_prior
         HIP_TRY(c, hipStreamSynchronize(s));
     }
     const int64_t pstride = (int64_t)rows * cols;
-    std::vector<int32_t> h_state((size_t)n * cols);
+    std::unique_ptr<int32_t[]> h_state(new int32_t[(size_t)n * cols]);      // [column][node]
 
     for (int k = 0; k < K; ++k)
         for (int64_t f0 = 0; f0 < c->Fp; f0 += cols) {
@@ -289,17 +344,20 @@ int reconstruct_impl(cafe_ctx* c, const cafe_params* pr, const float* root_prior
                 if (c->leaf_taxon[v] >= 0) {
                     const double* P = c->pool.base + (int64_t)slot * c->pool.stride;
                     const int32_t* cnt = c->d_counts + (int64_t)c->leaf_taxon[v] * c->Fp + f0;
-                    dim3 grid((unsigned)((ld + 255) / 256), (unsigned)((M + 8) / 8));
-                    if (mul) hipLaunchKernelGGL(recon_leaf_kernel<true>, grid, dim3(256), 0, s, P, c->pool.ld, cnt, dst, ld, M);
-                    else hipLaunchKernelGGL(recon_leaf_kernel<false>, grid, dim3(256), 0, s, P, c->pool.ld, cnt, dst, ld, M);
+                    dim3 grid((unsigned)((ld + 255) / 256), (unsigned)n_groups);
+                    int32_t* dfl = d_flags + (int64_t)bidx[par] * n_tiles * n_groups;
+                    if (mul) hipLaunchKernelGGL(recon_leaf_kernel<true>, grid, dim3(256), 0, s, P, c->pool.ld, cnt, dst, ld, M, dfl, n_groups);
+                    else hipLaunchKernelGGL(recon_leaf_kernel<false>, grid, dim3(256), 0, s, P, c->pool.ld, cnt, dst, ld, M, dfl, n_groups);
                 } else {
                     const double* Pt = c->kpool.base + (int64_t)slot * c->kpool.stride;
                     const double* B = d_B + (int64_t)bidx[v] * pstride;
                     const int n_ct = (int)(ld / 64), n_rg = (M + kRowsPerBlock - 1) / kRowsPerBlock;
                     dim3 grid((unsigned)(8 * ((n_ct + 7) / 8) * n_rg));
                     const int32_t* ext = c->kpool.ext ? c->kpool.ext + (size_t)slot * c->kpool.ext_blocks * 2 : nullptr;
-                    if (mul) hipLaunchKernelGGL(maxprod_kernel<true>, grid, dim3(256), 0, s, Pt, c->kpool.ld, B, dst, ld, M, c->kpool.rows, ext);
-                    else hipLaunchKernelGGL(maxprod_kernel<false>, grid, dim3(256), 0, s, Pt, c->kpool.ld, B, dst, ld, M, c->kpool.rows, ext);
+                    const int32_t* bfl = use_flags ? d_flags + (int64_t)bidx[v] * n_tiles * n_groups : nullptr;
+                    int32_t* dfl = d_flags + (int64_t)bidx[par] * n_tiles * n_groups;
+                    if (mul) hipLaunchKernelGGL(maxprod_kernel<true>, grid, dim3(256), 0, s, Pt, c->kpool.ld, B, dst, ld, M, c->kpool.rows, ext, bfl, dfl, n_groups);
+                    else hipLaunchKernelGGL(maxprod_kernel<false>, grid, dim3(256), 0, s, Pt, c->kpool.ld, B, dst, ld, M, c->kpool.rows, ext, bfl, dfl, n_groups);
                 }
                 HIP_TRY(c, hipGetLastError());
             }
@@ -317,17 +375,19 @@ int reconstruct_impl(cafe_ctx* c, const cafe_params* pr, const float* root_prior
                 }
                 const int slot = c->slot_of[(size_t)v * c->Kmax + k];
                 hipLaunchKernelGGL(backtrack_kernel, dim3((unsigned)(ld / 64)), dim3(256), 0, s, c->kpool.base + (int64_t)slot * c->kpool.stride, c->kpool.ld,
-                                   d_B + (int64_t)bidx[v] * pstride, ld, M, d_state + (int64_t)c->parent[v] * cols, d_state + (int64_t)v * cols);
+                                   d_B + (int64_t)bidx[v] * pstride, ld, M, d_state + (int64_t)c->parent[v] * cols, d_state + (int64_t)v * cols,
+                                   c->kpool.ext ? c->kpool.ext + (size_t)slot * c->kpool.ext_blocks * 2 : nullptr);
                 HIP_TRY(c, hipGetLastError());
             }
-            HIP_TRY(c, hipMemcpyAsync(h_state.data(), d_state, sizeof(int32_t) * (size_t)n * cols, hipMemcpyDeviceToHost, s));
+            hipLaunchKernelGGL(state_transpose_kernel, dim3(gb, (unsigned)((n + 15) / 16)), dim3(256), 0, s, d_state, n, cols, ld, d_state_t);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipMemcpyAsync(h_state.get(), d_state_t, sizeof(int32_t) * (size_t)n * ld, hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));
             // unique column -> every family that shares it
             for (int64_t f = 0; f < c->F_all; ++f) {
                 const int64_t u = c->ref_of[f];
                 if (u < f0 || u >= f0 + ld) continue;
-                int32_t* o = states + ((int64_t)k * c->F_all + f) * n;
-                for (int v = 0; v < n; ++v) o[v] = h_state[(size_t)v * cols + (u - f0)];
+                std::memcpy(states + ((int64_t)k * c->F_all + f) * n, h_state.get() + (size_t)(u - f0) * n, sizeof(int32_t) * n);
             }
         }
     c->upload_pending = false;

@@ -205,7 +205,7 @@ def test_reconstruction_chunked_and_duplicated_families(gr):
     assert whole.stats()["n_unique_families"] > 128
     n_interior = int((pb.leaf_taxon < 0).sum())
     rows = (pb.max_family_size + 1 + 3) // 4 * 4
-    small = capi.Context(pb, workspace_limit=(n_interior * rows * 8 + pb.n_nodes * 4) * 128 + 64)
+    small = capi.Context(pb, workspace_limit=(n_interior * rows * 8 + 2 * pb.n_nodes * 4 + n_interior * 4 + 1) * 128 + 64)
     assert np.array_equal(small.reconstruct(pr.lambdas, rp)[0], whole.reconstruct(pr.lambdas, rp)[0])
 
 
@@ -259,6 +259,37 @@ def test_bench_shape_sample_against_oracle():
     assert np.max(np.abs(rm[idx] / O.root_max(sub, lam, fast=True) - 1)) < 1e-10
     bp = ctx.branch_probabilities(lam, st)
     _check_bp(bp[idx], O.branch_probabilities(sub, lam, st[idx], fast=True), 1e-9)
+
+
+@pytest.mark.gpu
+def test_row_group_flags_change_no_state(monkeypatch):
+    """K5 walks a child panel only between its first and last non-zero row group (flags written by whoever wrote the panel,
+    reconstruct.hip), and the walk down scans a matrix row only inside K1's extent: every product left out has an exact
+    zero in it, so every state of every family equals the one found with the flags switched off (CAFE_NO_RECON_FLAGS) --
+    short and long branches, two rates, gamma categories, families that are extinct or sit on one taxon."""
+    from cafexp_amd import capi, problem as P, synth
+    pb, _ = synth.make_problem(n_taxa=33, n_families=1500, max_count=420, lam_sim=0.003, seed=5, root_cap=200, lambda_clade_min=4)
+    assert pb.matrix_size >= 256 and pb.n_lambdas == 2
+    pb.counts[3, :] = 0
+    pb.counts[4, :] = 0
+    pb.counts[4, 7] = 300
+    jmax = min(pb.max_family_size, pb.max_root_family_size)
+    rp = np.zeros(jmax + 1, dtype=np.float32)
+    rp[:pb.max_root_family_size] = P.prior_uniform(pb.max_root_family_size)[:jmax + 1]
+    _, mult = O.discrete_gamma(3, 0.7)
+    calls = [(np.array([0.0004, 0.003]), None), (np.array([0.006, 0.0002]), mult)]
+    ctx = capi.Context(pb, max_categories=3)
+    got = [ctx.reconstruct(lam, rp, multipliers=m) for lam, m in calls]
+    monkeypatch.setenv("CAFE_NO_RECON_FLAGS", "1")
+    plain = capi.Context(pb, max_categories=3)
+    for (lam, m), g in zip(calls, got):
+        assert np.array_equal(g, plain.reconstruct(lam, rp, multipliers=m))
+    idx = np.array([3, 4, 5, 900])
+    import dataclasses
+    sub = dataclasses.replace(pb, counts=np.ascontiguousarray(pb.counts[idx]), family_ids=[pb.family_ids[i] for i in idx])
+    lam = calls[0][0]
+    pr = P.Params(lambdas=lam, prior=P.prior_uniform(pb.max_root_family_size))
+    _near_tie_only(sub, pr, rp, got[0][0][idx], O.reconstruct(sub, lam, rp, fast=True)[0], 1.0)
 
 
 @pytest.mark.gpu
