@@ -1453,9 +1453,20 @@ double count_executed_flops(cafe_ctx* c, std::vector<double>* per_launch = nullp
                         if (have_b) { lo = std::max(lo, bext[((size_t)k * n_ct + ct) * 2]); hi = std::min(hi, bext[((size_t)k * n_ct + ct) * 2 + 1]); }
                         if (hi < lo) { lo = 0; hi = 0; }
                         hi = std::min(hi, c->M);
-                        const int nkt = hi / kBK - lo / kBK + 1;
-                        const int kk = std::min(nkt * kBK, c->M + 1 - (lo / kBK) * kBK);      // the last K tile of the matrix is ragged
-                        executed += 2.0 * std::min(bm, rows - row0) * (double)kk * (have_b ? (double)kBN : (double)cols);
+                        // the tile runs K tiles lo/kb .. hi/kb; its row block b issues MFMAs only in those inside ITS OWN extent
+                        // (prune_gemm.hip, block_ranges); the last K tile of the matrix is ragged
+                        const int t_lo = lo / kBK, t_hi = hi / kBK;
+                        for (int b = row0 / 16; b < row0 / 16 + mi && b * 16 < rows; ++b) {
+                            int b_lo = t_lo, b_hi = t_hi;
+                            if (e) {
+                                if (b >= nb || e[2 * b + 1] < e[2 * b]) continue;
+                                b_lo = std::max(t_lo, e[2 * b] / kBK);
+                                b_hi = std::min(t_hi, e[2 * b + 1] / kBK);
+                            }
+                            if (b_hi < b_lo) continue;
+                            const int kk = std::min((b_hi - b_lo + 1) * kBK, c->M + 1 - b_lo * kBK);
+                            executed += 2.0 * std::min(16, rows - b * 16) * (double)kk * (have_b ? (double)kBN : (double)cols);
+                        }
                     }
                 }
             }

@@ -188,6 +188,37 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI, KB)) void prune_gemm_
         __builtin_amdgcn_raw_ptr_buffer_load_lds(x.rsB, (lptr_t)(Bs + krow * kBStride), 16, lane16, ((k0 + krow) * x.ldb + x.col0) * 8, 0, 0);
     };
 
+    // Which of the tile's MI row blocks take part in K tile kt of its range: block i only inside ITS OWN matrix extent (the tile's
+    // range is the hull of them, cut by the panel's extent).  The band of a transition matrix moves down by 16 rows per block, so
+    // the first K tiles of a range meet only the upper blocks and the last ones only the lower blocks -- a tenth of the MFMAs of
+    // a config-4 call multiply a zero block of A; leaving them out changes no accumulator bit.  All scalar.
+    typedef const __attribute__((address_space(4))) int32_t* ext_cptr_t;
+    struct Blocks { int lo[MI], hi[MI]; };                  // K tiles relative to the tile's first one; lo > hi: never
+    auto block_ranges = [&](const Tile& x) -> Blocks {
+        Blocks b;
+        if (!a.pool.ext) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) { b.lo[i] = 0; b.hi[i] = 0x7fff; }
+            return b;
+        }
+        const ext_cptr_t e = (ext_cptr_t)(unsigned long long)(a.pool.ext + ((int64_t)x.o->slot[x.cat] * a.pool.ext_blocks + x.row_tile * MI) * 2);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            int lo = 1, hi = 0;
+            if (x.row_tile * MI + i < a.pool.ext_blocks) { lo = e[2 * i]; hi = e[2 * i + 1]; }
+            const bool some = hi >= lo;
+            b.lo[i] = some ? lo / KB - x.kt0 : 1;
+            b.hi[i] = some ? hi / KB - x.kt0 : 0;
+        }
+        return b;
+    };
+    auto active = [&](const Blocks& b, int kt) -> unsigned {
+        unsigned m = 0;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) m |= (unsigned)(kt >= b.lo[i] && kt <= b.hi[i]) << i;
+        return m;
+    };
+
     int2 e_cur = entry(0);
     if (e_cur.y == 0) return;
     {
@@ -233,6 +264,7 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI, KB)) void prune_gemm_
             for (int i = 0; i < MI; ++i) af[i] = base[a_off + i * 16];
             read_b(base, 0, bfr[0]);
         }
+        const Blocks blk = block_ranges(cur);
         const int nkt = cur.nkt, kbase = cur.kt0 * KB;     // this tile's K tiles: kbase, kbase + 16, ...
         const int steps_last = cur.kt0 + nkt == n_k ? last_steps : NS;  // only the matrix's last K tile is ragged
         for (int kt = 0; kt + 1 < nkt; ++kt) {
@@ -241,6 +273,7 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI, KB)) void prune_gemm_
             const double* nbase = lds + (buf ^ 1) * STAGE;
             const int k1 = kbase + (kt + 1) * KB;          // K tile being staged into the other stage
             const bool next_full = kt + 2 < nkt;            // K tile kt+1 is another pipelined one (not this tile's last)
+            const unsigned on = active(blk, kt);
 #pragma unroll
             for (int s4 = 0; s4 < NS; ++s4) {
                 if (s4 < NS - 1) {
@@ -257,12 +290,14 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI, KB)) void prune_gemm_
                 if (pre) read_b(src, ns, bfr[(s4 + 1) & 1]);
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
-                    if (TRANS) {                            // operands swapped: the accumulators hold C^T
-                        acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfr[s4 & 1][0], af[i], acc[i][0], 0, 0, 0);
-                        acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfr[s4 & 1][1], af[i], acc[i][1], 0, 0, 0);
-                    } else {
-                        acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bfr[s4 & 1][0], acc[i][0], 0, 0, 0);
-                        acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bfr[s4 & 1][1], acc[i][1], 0, 0, 0);
+                    if (on & (1u << i)) {
+                        if (TRANS) {                        // operands swapped: the accumulators hold C^T
+                            acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfr[s4 & 1][0], af[i], acc[i][0], 0, 0, 0);
+                            acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfr[s4 & 1][1], af[i], acc[i][1], 0, 0, 0);
+                        } else {
+                            acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bfr[s4 & 1][0], acc[i][0], 0, 0, 0);
+                            acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bfr[s4 & 1][1], acc[i][1], 0, 0, 0);
+                        }
                     }
                     if (pre) af[i] = src[a_off + ns * 4 * SA + i * 16];
                     __builtin_amdgcn_sched_barrier(0);      // keep "two MFMAs, then the read that reuses their register"
@@ -280,6 +315,7 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI, KB)) void prune_gemm_
 #pragma unroll
                 for (int q = 1; q < NS; ++q) stage_quarter(nxt, nk0, buf ^ 1, q);
             }
+            const unsigned on = active(blk, nkt - 1);
 #pragma unroll
             for (int s4 = 0; s4 < NS; ++s4) {
                 if (s4 < steps_last) {
@@ -288,6 +324,7 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI, KB)) void prune_gemm_
                     read_b(base, s4, bfr[0]);
 #pragma unroll
                     for (int i = 0; i < MI; ++i) {
+                        if (!(on & (1u << i))) continue;
                         if (TRANS) {
                             acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfr[0][0], af[i], acc[i][0], 0, 0, 0);
                             acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfr[0][1], af[i], acc[i][1], 0, 0, 0);
