@@ -37,6 +37,13 @@
 
 #include "cafe_kernels.h"
 
+// Measurement only: built with -D'CAFE_EXPERIMENT_B_COLUMN(c)=0' every workgroup stages column tile 0 of
+// the child panel, so that every B fetch after the first is an L2 hit -- wrong results, the same work: what the refetches of
+// the child panel cost (0.9 % of an every-K-tile call).
+#ifndef CAFE_EXPERIMENT_B_COLUMN
+#define CAFE_EXPERIMENT_B_COLUMN(c) (c)
+#endif
+
 namespace cafe {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI, KB)) void prune_gemm_
             if (nl == 64 || lane < nl)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(x.rsA, (lptr_t)(As + krow * SA), 16, lane16, ((k0 + krow) * lda + x.row0) * 8, 0, 0);
         }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(x.rsB, (lptr_t)(Bs + krow * kBStride), 16, lane16, ((k0 + krow) * x.ldb + x.col0) * 8, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x.rsB, (lptr_t)(Bs + krow * kBStride), 16, lane16, ((k0 + krow) * x.ldb + CAFE_EXPERIMENT_B_COLUMN(x.col0)) * 8, 0, 0);
     };
 
     // Which of the tile's MI row blocks take part in K tile kt of its range: block i only inside ITS OWN matrix extent (the tile's

@@ -37,4 +37,11 @@ timeout -k 10 200 python3 tools/launch_table.py 3/8 > $OUT/launch_table_shard3.t
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_shard -o run --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --emulate-shard 3/8 > $OUT/prof_shard.log 2>&1
 find $OUT/prof_shard -name "*kernel_trace.csv" -delete
+echo "[9] second-tier paths at the bench shape: reconstruction (kernel trace), p-values"
+rm -rf $OUT/prof_recon
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_recon -o run --output-format csv -- python3 $R/tools/reconstruct_scale.py > $OUT/prof_recon.log 2>&1
+find $OUT/prof_recon -name "*kernel_trace.csv" -delete
+cd $R
+timeout -k 10 300 python3 tools/reconstruct_scale.py 2>/dev/null | grep -v amdgpu > $OUT/reconstruct_scale.log
+timeout -k 10 300 python3 tools/pvalues_scale.py 2>/dev/null | grep -v amdgpu > $OUT/pvalues_scale.log || true
 cd $R
