@@ -284,12 +284,24 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI, KB)) void prune_gemm_
 #pragma unroll
             for (int s4 = 0; s4 < NS; ++s4) {
                 if (s4 < NS - 1) {
-                    if (s4 == 0 && kt == 0) stage_quarter(cur, k1, buf ^ 1, 0);   // no earlier step to carry it
-                    stage_quarter(cur, k1, buf ^ 1, s4 + 1);
+                    if (s4 == 0 && kt == 0) {               // K tile 1 of this output tile: no earlier barrier to carry it
+#pragma unroll
+                        for (int q = 0; q < NS; ++q) stage_quarter(cur, k1, buf ^ 1, q);
+                    }
                 } else {
-                    __syncthreads();                        // K tile kt+1 has landed; every wave has read all of K tile kt
-                    if (next_full) stage_quarter(cur, k1 + KB, buf, 0);
-                    else if (has_next) stage_quarter(nxt, nxt.kt0 * KB, buf, 0);
+                    // K tile kt+1 has landed; every wave has read all of K tile kt (the fragments of its last step are in
+                    // registers), so ALL of K tile kt+2 goes out here, a whole K tile ahead of the barrier that needs it.
+                    // (Until the middle of round 3 only its first quarter left here and the others one step before they
+                    // were needed: with 8-deep K tiles that was a lead of one k-step -- 0.4 us of a wave's time where only two
+                    // of a tile's five row blocks are live, less than a fetch from the Infinity Cache takes.)
+                    __syncthreads();
+                    if (next_full) {
+#pragma unroll
+                        for (int q = 0; q < NS; ++q) stage_quarter(cur, k1 + KB, buf, q);
+                    } else if (has_next) {
+#pragma unroll
+                        for (int q = 0; q < NS; ++q) stage_quarter(nxt, nxt.kt0 * KB, buf, q);
+                    }
                 }
                 const bool pre = s4 < NS - 1 || next_full;  // uniform
                 const double* src = s4 < NS - 1 ? base : nbase;
@@ -313,14 +325,13 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI, KB)) void prune_gemm_
             ++g;
         }
         {   // last K tile: last_steps of its four steps hold valid k; plain read -> MFMA steps.  The next output tile's
-            // first K tile rides along (its first quarter went out in front of this tile unless this is the only one).
+            // first K tile is in flight (it went out at the barrier of the K tile before, or goes out here if this is the only one).
             const int buf = g & 1;
             const double* base = lds + buf * STAGE;
-            if (has_next) {
+            if (has_next && nkt == 1) {                     // (otherwise it went out at the barrier of the K tile before)
                 const int nk0 = nxt.kt0 * KB;
-                if (nkt == 1) stage_quarter(nxt, nk0, buf ^ 1, 0);
 #pragma unroll
-                for (int q = 1; q < NS; ++q) stage_quarter(nxt, nk0, buf ^ 1, q);
+                for (int q = 0; q < NS; ++q) stage_quarter(nxt, nk0, buf ^ 1, q);
             }
             const unsigned on = active(blk, nkt - 1);
 #pragma unroll
