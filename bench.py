@@ -434,6 +434,7 @@ def main():
         fence()
     # what the K2 launches of a step really executed (the same every step: same parameters); counted once, outside the timing
     flops_executed = ctx.executed_flops() * n_prof
+    flops_tile_ranges = ctx.tile_range_flops() * n_prof
     if dist_on:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if native_comm else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -472,9 +473,13 @@ def main():
                          "measured": "HIP events on every K2 dispatch of the timed steps" if live_events
                                      else "HIP events on every K2 dispatch of one step behind the timed region (rank 0's shard)",
                          "avg_launch_ms": ms_gemm / max(1, launches), "flops_per_launch": flops_executed / max(1, launches),
-                         # flops_per_launch = what the launches EXECUTE: columns = distinct subtree patterns, K tiles = those
-                         # inside a row tile's non-zero extent (DESIGN.md sections 2, 3).  With every K tile of those
-                         # columns, and with one column per family at every node (SURVEY 8d's per-family figure):
+                         # flops_per_launch = the flops of the MFMAs the launches ISSUE: columns = distinct subtree patterns, K
+                         # tiles = those inside a row tile's non-zero extent, each 16-row block of the tile over its own extent
+                         # only (DESIGN.md sections 2, 3).  Then: every block over its tile's whole K range (the count rounds 2
+                         # and 3a quoted `frac` on: the kernel issued those MFMAs then), every K tile of the distinct columns,
+                         # one column per family at every node (SURVEY 8d's per-family figure):
+                         "flops_per_launch_whole_tile_ranges": flops_tile_ranges / max(1, launches),
+                         "frac_over_whole_tile_ranges": flops_tile_ranges / (ms_gemm * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS if ms_gemm > 0 else None,
                          "flops_per_launch_all_k_tiles": flops / max(1, launches),
                          "flops_per_launch_one_column_per_family": flops_fam / max(1, launches)},
             "phases_ms_per_step": {"bd_matrix_build": ms_mat / n_prof, "prune_total": ms_prune / n_prof,

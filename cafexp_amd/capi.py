@@ -69,7 +69,7 @@ EXPORTS = [
     "cafe_root_max", "cafe_reconstruct", "cafe_branch_probabilities", "cafe_pvalues", "cafe_debug_force_tile",
     "cafe_comm_unique_id", "cafe_comm_attach", "cafe_comm_detach", "cafe_shard_plan", "cafe_shard_plan_scaled", "cafe_create_sharded",
     "cafe_sharded_destroy", "cafe_sharded_last_error", "cafe_sharded_score", "cafe_sharded_family_results",
-    "cafe_sharded_size", "cafe_sharded_context", "cafe_set_graphs", "cafe_executed_flops", "cafe_get_extents", "cafe_debug_launch_flops", "cafe_debug_launch_ms", "cafe_debug_plan_check",
+    "cafe_sharded_size", "cafe_sharded_context", "cafe_set_graphs", "cafe_executed_flops", "cafe_debug_tile_range_flops", "cafe_get_extents", "cafe_debug_launch_flops", "cafe_debug_launch_ms", "cafe_debug_plan_check",
     "cafe_debug_fail_next", "cafe_debug_column_extents", "cafe_debug_leaf_transposes",
 ]
 CAFE_COMM_ID_BYTES = 128
@@ -468,6 +468,14 @@ class Context:
         """Flops the K2 launches of the last call really ran (K tiles outside matrix extent x panel extent are skipped)."""
         v = C.c_double()
         self._check(self._lib.cafe_executed_flops(self._h, C.byref(v)))
+        return v.value
+
+    def tile_range_flops(self) -> float:
+        """The same with every row block of a tile counted over the tile's whole K range (cafe_debug_tile_range_flops)."""
+        self._lib.cafe_debug_tile_range_flops.restype = C.c_int
+        self._lib.cafe_debug_tile_range_flops.argtypes = [C.c_void_p, _f64p]
+        v = C.c_double()
+        self._check(self._lib.cafe_debug_tile_range_flops(self._h, C.byref(v)))
         return v.value
 
     def debug_stamps(self, words: int) -> np.ndarray:

@@ -1416,7 +1416,9 @@ int enqueue(cafe_ctx* c, const cafe_params* pr, double* d_out, hipStream_t s, bo
 // Flops the K2 launches of the last (profiled) call EXECUTED: a (row tile, column tile) pair runs only the K tiles inside
 // matrix extent x panel extent, so read the extents this call published and count, per launch, what its tiles ran.  Reads
 // the extents back (a few synchronous copies, milliseconds of host work): for measurement, once, not per call.
-double count_executed_flops(cafe_ctx* c, std::vector<double>* per_launch = nullptr) {
+// per_block: count a row block only over the K tiles inside its own extent (what the kernel issues); false: every block over
+// its tile's whole K range (the count of rounds 2 and 3a, kept for comparison)
+double count_executed_flops(cafe_ctx* c, std::vector<double>* per_launch = nullptr, bool per_block = true) {
     if (c->gemm_launches_info.empty()) return c->stats.gemm_flops;
     const int kBK = c->kb;
     const int nb = c->kpool.ext_blocks;
@@ -1458,7 +1460,7 @@ double count_executed_flops(cafe_ctx* c, std::vector<double>* per_launch = nullp
                         const int t_lo = lo / kBK, t_hi = hi / kBK;
                         for (int b = row0 / 16; b < row0 / 16 + mi && b * 16 < rows; ++b) {
                             int b_lo = t_lo, b_hi = t_hi;
-                            if (e) {
+                            if (e && per_block) {
                                 if (b >= nb || e[2 * b + 1] < e[2 * b]) continue;
                                 b_lo = std::max(t_lo, e[2 * b] / kBK);
                                 b_hi = std::min(t_hi, e[2 * b + 1] / kBK);
@@ -1801,6 +1803,17 @@ int cafe_debug_column_extents(cafe_ctx* ctx, int32_t node, int32_t category, int
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
     HIP_TRY(ctx, hipMemcpy(out, ctx->d_colext[node] + (size_t)category * cols * 2, sizeof(int32_t) * 2 * cols, hipMemcpyDeviceToHost));
+    return CAFE_OK;
+}
+
+int cafe_debug_tile_range_flops(cafe_ctx* ctx, double* flops) {
+    if (!ctx || !flops) return CAFE_ERR_ARGUMENT;
+    if (!ctx->have_results || ctx->gemm_launches_info.empty()) { set_err(ctx, "cafe_debug_tile_range_flops: no completed call that was enqueued launch by launch"); return CAFE_ERR_STATE; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+    const double v = count_executed_flops(ctx, nullptr, false);
+    if (v < 0) { set_err(ctx, "cafe_debug_tile_range_flops: reading the extents back failed"); return CAFE_ERR_DEVICE; }
+    *flops = v;
     return CAFE_OK;
 }
 

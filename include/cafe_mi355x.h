@@ -257,10 +257,14 @@ int cafe_debug_column_extents(cafe_ctx* ctx, int32_t node, int32_t category, int
 int cafe_debug_leaf_transposes(cafe_ctx* ctx, int32_t* n_branches, int32_t* used_by_last_call);
 int cafe_get_stats(const cafe_ctx* ctx, cafe_stats* stats);
 /* Flops the K2 launches of the last call executed: a (row tile, column tile) pair runs only the K tiles inside the
- * intersection of the matrix's non-zero extent (K1) and the panel's (extents.hip) -- the products it leaves out all have an
- * exact zero in them.  Reads the extents back and counts on the host (milliseconds): measurement only.  Needs a call that
+ * intersection of the matrix's non-zero extent (K1) and the panel's (extents.hip), and of those each 16-row block of the tile
+ * only the ones inside its own extent -- the products left out all have an exact zero in them.  Reads the extents back and counts on the host (milliseconds): measurement only.  Needs a call that
  * was enqueued launch by launch (no graph replay). */
 int cafe_executed_flops(cafe_ctx* ctx, double* flops);
+/* diagnostic: the same count with every 16-row block of a tile taken over the tile's WHOLE K range (the hull of its blocks'
+ * ranges) -- what the kernel issued until each block got its own range (prune_gemm.hip, block_ranges), and what rounds 2 and
+ * 3a quoted their roofline fractions on; >= cafe_executed_flops */
+int cafe_debug_tile_range_flops(cafe_ctx* ctx, double* flops);
 /* diagnostic: the same per K2 launch of the last call, in launch order (executed[n], all_k_tiles[n] and tile_height[n] may be
  * NULL); n = cafe_stats.gemm_launches */
 int cafe_debug_launch_flops(cafe_ctx* ctx, double* executed, double* all_k_tiles, int32_t* tile_height, size_t n);
