@@ -33,6 +33,12 @@
 // copies that row (prune_gemm.hip).
 #include "cafe_kernels.h"
 
+// diagnostic: -D'CAFE_EXPERIMENT_K1_STORE_IF=&& n < 0' builds K1 without its global stores (the matrices are wrong): what is
+// left is the latency chain of the row steps, DESIGN.md section 3 K1
+#ifndef CAFE_EXPERIMENT_K1_STORE_IF
+#define CAFE_EXPERIMENT_K1_STORE_IF
+#endif
+
 namespace cafe {
 
 // DPP move of a double (two 32-bit halves); lanes without a source read 0
@@ -80,6 +86,19 @@ __device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, cons
     // the only synchronisation) and leaves as 1 KB contiguous per store instruction.
     __shared__ double2 rowbuf[64 * E / 2];
     auto store_row = [&](int r, const double* v) {
+        if constexpr (E <= 4) {
+            // small orders: a matrix is a chain of short row steps, not a stream of lines, and the LDS round trip with its two
+            // waits is a third of a step.  The lane stores its own columns (pieces 8*E bytes apart: the row is 1-2 KB).
+            double2* row = reinterpret_cast<double2*>(P + (int64_t)r * ld);
+#pragma unroll
+            for (int i = 0; i < E; i += 2) {
+                double2 w;
+                w.x = (c0 + i < n) ? v[i] : 0.0;
+                w.y = (c0 + i + 1 < n) ? v[i + 1] : 0.0;
+                if (j0 + i < ld CAFE_EXPERIMENT_K1_STORE_IF) row[(j0 + i) >> 1] = w;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < E; i += 2) {
             double2 w;
@@ -93,7 +112,7 @@ __device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, cons
 #pragma unroll
         for (int i = 0; i < E / 2; ++i) {
             const int q = lane + 64 * i;                 // 16-byte piece of the row
-            if (2 * q < ld) row[q] = rowbuf[q];
+            if (2 * q < ld CAFE_EXPERIMENT_K1_STORE_IF) row[q] = rowbuf[q];
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);          // the pieces are in registers before the next row overwrites the buffer
         __asm__ volatile("" ::: "memory");

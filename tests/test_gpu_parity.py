@@ -38,7 +38,9 @@ def _ab_problem(newick, counts, M, R, **kw):
 # ------------------------------------------------------------------ K1
 @pytest.mark.parametrize("n,lam,t", [(5, 0.05, 5.0), (141, 0.006335, 68.7105), (141, 0.006335, 68.0), (141, 0.01, 96.435575),
                                      (10, 0.05, 25.0), (12, 0.02, 25.0), (21, 0.045, 3.0), (64, 0.002, 0.0004), (300, 0.003, 40.0),
-                                     (17, 0.5, 1.0), (130, 1e-5, 0.01), (751, 0.0053, 53.667)])
+                                     (17, 0.5, 1.0), (130, 1e-5, 0.01), (751, 0.0053, 53.667),
+                                     # the orders either side of a change of columns per lane (2 | 4 | 6: up to 4 a lane stores its own columns)
+                                     (128, 0.01, 30.0), (129, 0.01, 30.0), (256, 0.004, 50.0), (257, 0.004, 50.0)])
 @pytest.mark.parametrize("layout", [0, 1])
 def test_matrix_build_vs_oracle(capi, oracle, n, lam, t, layout):
     """layout 0: row-major matrices of leaf branches; layout 1: the k-major operand of interior branches,

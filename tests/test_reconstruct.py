@@ -210,6 +210,28 @@ def test_reconstruction_chunked_and_duplicated_families(gr):
 
 
 @pytest.mark.gpu
+def test_repeated_calls_on_one_context_change_no_state(gr):
+    """cafe_reconstruct shares the context's matrix pools and stream with the scorer: a second call, a call with categories
+    after a base call, and a call after a scorer call on the same context return what a fresh context returns."""
+    from cafexp_amd import capi, problem as P
+    from cafexp_amd.gamma_rates import discrete_gamma
+    pb, pr, rp, perm = _case(gr["mammals_base"])
+    _, mult = discrete_gamma(3, 0.7)
+    ctx = capi.Context(pb, max_categories=3)
+    first = ctx.reconstruct(pr.lambdas, rp)
+    assert np.array_equal(ctx.reconstruct(pr.lambdas, rp), first)
+    cats = ctx.reconstruct(pr.lambdas, rp, multipliers=mult)
+    ctx.score(P.Params(lambdas=pr.lambdas, prior=P.prior_uniform(pb.max_root_family_size)))
+    assert np.array_equal(ctx.reconstruct(pr.lambdas, rp), first)
+    assert np.array_equal(ctx.reconstruct(pr.lambdas, rp, multipliers=mult), cats)
+    ctx.close()
+    fresh = capi.Context(pb, max_categories=3)
+    assert np.array_equal(fresh.reconstruct(pr.lambdas, rp, multipliers=mult), cats)
+    assert np.array_equal(fresh.reconstruct(pr.lambdas, rp), first)
+    fresh.close()
+
+
+@pytest.mark.gpu
 def test_polytomies_and_extinct_families():
     """Multifurcating nodes (a leaf child of the root, a 3-way interior node) and all-zero / single-taxon families:
     reconstruction, Viterbi sums and root maxima against the oracle (the reference walks `_descendants` generically)."""
