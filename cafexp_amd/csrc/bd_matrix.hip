@@ -113,7 +113,7 @@ __device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, cons
 #pragma unroll
         for (int i = 0; i < E / 2; ++i) {
             const int q = lane + 64 * i;                 // 16-byte piece of the row
-            if (2 * q < ld CAFE_EXPERIMENT_K1_STORE_IF) row[q] = rowbuf[q];
+            if (2 * q < ld CAFE_EXPERIMENT_K1_STORE_IF) row[q] = rowbuf[q];      // (non-temporal stores measured: 1.24 -> 1.29-1.33 ms at order 751)
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);          // the pieces are in registers before the next row overwrites the buffer
         __asm__ volatile("" ::: "memory");

@@ -43,6 +43,22 @@
 #ifndef CAFE_EXPERIMENT_B_COLUMN
 #define CAFE_EXPERIMENT_B_COLUMN(c) (c)
 #endif
+// Cache policy of K2's three streams (the aux operand of the buffer instructions: 1 = sc0, 2 = nt, 16 = sc1): the k-major
+// matrix tiles (A), the child panel's K tiles (B, LDS-DMA both) and the stores of the output panel (C).  Measured at config 4
+// (one process per build, K2 per call): everything 0 117.4-117.8 ms; B loads nt 122.3; A loads nt
+// 128.1 (both streams live on their L2 hits); C stores nt 117.0-117.5; C stores nt + sc1 116.9; C stores sc1 117.7.  The
+// output panel is written once and read again a launch later from HBM whatever the policy, so the variants with 8-deep
+// K tiles (matrix orders >= 256, where a panel is far larger than the L2s) store it non-temporal and leave the L2s to A and
+// B; the small-order variants keep the default (their whole panel fits the L2s and the next launch reads it from there).
+#ifndef CAFE_K2_A_LOAD_AUX
+#define CAFE_K2_A_LOAD_AUX 0
+#endif
+#ifndef CAFE_K2_B_LOAD_AUX
+#define CAFE_K2_B_LOAD_AUX 0
+#endif
+#ifndef CAFE_K2_C_STORE_AUX
+#define CAFE_K2_C_STORE_AUX (KB == 8 ? 2 : 0)
+#endif
 
 namespace cafe {
 
@@ -186,13 +202,13 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI, KB)) void prune_gemm_
             const int soff = (k0 * lda + x.row0) * 8;
 #pragma unroll
             for (int j = 0; j < PER; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(x.rsA, (lptr_t)(As + a_dst[q][j]), 16, a_voff[q][j], soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x.rsA, (lptr_t)(As + a_dst[q][j]), 16, a_voff[q][j], soff, 0, CAFE_K2_A_LOAD_AUX);
         } else {
             constexpr int nl = BM >= 128 ? 64 : BM / 2;
             if (nl == 64 || lane < nl)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(x.rsA, (lptr_t)(As + krow * SA), 16, lane16, ((k0 + krow) * lda + x.row0) * 8, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x.rsA, (lptr_t)(As + krow * SA), 16, lane16, ((k0 + krow) * lda + x.row0) * 8, 0, CAFE_K2_A_LOAD_AUX);
         }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(x.rsB, (lptr_t)(Bs + krow * kBStride), 16, lane16, ((k0 + krow) * x.ldb + CAFE_EXPERIMENT_B_COLUMN(x.col0)) * 8, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x.rsB, (lptr_t)(Bs + krow * kBStride), 16, lane16, ((k0 + krow) * x.ldb + CAFE_EXPERIMENT_B_COLUMN(x.col0)) * 8, 0, CAFE_K2_B_LOAD_AUX);
     };
 
     // Which of the tile's MI row blocks take part in K tile kt of its range: block i only inside ITS OWN matrix extent (the tile's
@@ -438,7 +454,7 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI, KB)) void prune_gemm_
                         for (int j = 0; j < 2; ++j) {
                             const double v = acc[i][j][r];      // (a bit_cast straight from the vector element stores element 0)
                             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(int2_t, v), cur.rsC, c_voff,
-                                                                  c_soff0 + ((j * 16 + r * 4) * ldt + i * 16) * 8, 0);
+                                                                  c_soff0 + ((j * 16 + r * 4) * ldt + i * 16) * 8, CAFE_K2_C_STORE_AUX);
                         }
                     }
                 } else if (decltype(full)::value || step + l4 < rows_here) {
@@ -446,7 +462,7 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI, KB)) void prune_gemm_
                     for (int j = 0; j < 2; ++j) {
                         double v = acc[i][j][r];
                         if (MUL || LEAF) v *= p.f[j][r];
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(int2_t, v), cur.rsC, c_voff, c_soff0 + (step * ldb + j * 16) * 8, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(int2_t, v), cur.rsC, c_voff, c_soff0 + (step * ldb + j * 16) * 8, CAFE_K2_C_STORE_AUX);
                     }
                 }
             }
