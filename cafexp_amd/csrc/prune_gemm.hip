@@ -40,6 +40,14 @@
 // Measurement only: built with -D'CAFE_EXPERIMENT_B_COLUMN(c)=0' every workgroup stages column tile 0 of
 // the child panel, so that every B fetch after the first is an L2 hit -- wrong results, the same work: what the refetches of
 // the child panel cost (0.9 % of an every-K-tile call).
+// Likewise for the matrix tiles: -D'CAFE_EXPERIMENT_A_SLOT(s)=0' -D'CAFE_EXPERIMENT_A_ROW(r)=0' makes every workgroup stage rows of
+// ONE matrix at row tile 0 (wrong results, same work): what the L2 misses of the A stream cost.
+#ifndef CAFE_EXPERIMENT_A_SLOT
+#define CAFE_EXPERIMENT_A_SLOT(s) (s)
+#endif
+#ifndef CAFE_EXPERIMENT_A_ROW
+#define CAFE_EXPERIMENT_A_ROW(r) (r)
+#endif
 #ifndef CAFE_EXPERIMENT_B_COLUMN
 #define CAFE_EXPERIMENT_B_COLUMN(c) (c)
 #endif
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI, KB)) void prune_gemm_
         x.cat = pair / nct;
         x.row0 = x.row_tile * BM;
         x.col0 = ct * kBN;
-        x.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.pool.base + (int64_t)x.o->slot[x.cat] * a.pool.stride), 0, (int)(a.pool.stride * 8), 0x00020000);
+        x.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.pool.base + (int64_t)CAFE_EXPERIMENT_A_SLOT(x.o->slot[x.cat]) * a.pool.stride), 0, (int)(a.pool.stride * 8), 0x00020000);
         x.rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(x.o->src + (int64_t)x.cat * x.o->src_kstride), 0, span_bytes(x.o->src_kstride), 0x00020000);
         x.rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(x.o->dst + (int64_t)x.cat * x.o->dst_kstride), 0, span_bytes(x.o->dst_kstride), 0x00020000);
         x.kt0 = en.y >> 16;
@@ -202,14 +210,14 @@ __global__ __launch_bounds__(256, prune_gemm_wg_per_cu(MI, KB)) void prune_gemm_
         double* Bs = As + A_TILE;
         const int krow = q * 4 + wave;
         if (A_CONTIG) {
-            const int soff = (k0 * lda + x.row0) * 8;
+            const int soff = (k0 * lda + CAFE_EXPERIMENT_A_ROW(x.row0)) * 8;
 #pragma unroll
             for (int j = 0; j < PER; ++j)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(x.rsA, (lptr_t)(As + a_dst[q][j]), 16, a_voff[q][j], soff, 0, CAFE_K2_A_LOAD_AUX);
         } else {
             constexpr int nl = BM >= 128 ? 64 : BM / 2;
             if (nl == 64 || lane < nl)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(x.rsA, (lptr_t)(As + krow * SA), 16, lane16, ((k0 + krow) * lda + x.row0) * 8, 0, CAFE_K2_A_LOAD_AUX);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x.rsA, (lptr_t)(As + krow * SA), 16, lane16, ((k0 + krow) * lda + CAFE_EXPERIMENT_A_ROW(x.row0)) * 8, 0, CAFE_K2_A_LOAD_AUX);
         }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(x.rsB, (lptr_t)(Bs + krow * kBStride), 16, lane16, ((k0 + krow) * x.ldb + CAFE_EXPERIMENT_B_COLUMN(x.col0)) * 8, 0, CAFE_K2_B_LOAD_AUX);
     };
