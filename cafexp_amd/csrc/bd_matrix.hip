@@ -89,7 +89,7 @@ __device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, cons
     auto store_row = [&](int r, const double* v) {
         if constexpr (E <= 4) {
             // small orders: a matrix is a chain of short row steps, not a stream of lines, and the LDS round trip with its two
-            // waits is a third of a step.  The lane stores its own columns (pieces 8*E bytes apart: the row is 1-2 KB).
+            // waits is a seventh of a step (mammals K1 59.5 -> 51 us).  The lane stores its own columns (pieces 8*E bytes apart: the row is 1-2 KB).
             double2* row = reinterpret_cast<double2*>(P + (int64_t)r * ld);
 #pragma unroll
             for (int i = 0; i < E; i += 2) {
