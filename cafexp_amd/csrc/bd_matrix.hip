@@ -130,6 +130,7 @@ __device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, cons
 #pragma unroll
     for (int i = 0; i < (KMAJOR ? 1 : E); ++i) { col_first[i] = 0x7fffffff; col_last[i] = -1; }
     auto note = [&](int r, const double* v) {
+        if (!pool.ext) return;                         // (uniform) orders below 256 publish no extents: nothing to track in the row step
         if (KMAJOR) {
             bool any = false;
 #pragma unroll
