@@ -77,6 +77,14 @@ __device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, cons
     const double w15 = pow(apow[E - 1], (double)((lane & 15) + 1));
     const double w31 = lane >= 32 ? pow(apow[E - 1], (double)(lane - 31)) : 0.0;
 
+    // Columns past the matrix (c0 + i >= n: the tail of the last lanes) must be stored as zeros.  Up to E = 16 they ARE zeros: the
+    // lane multiplies h by a per-element (1-a)^2 that is 0 there, so p stays exactly 0 (a p + 0 h) and nothing is masked per
+    // row step -- 2 E selects less of its ~200 instructions; columns inside the matrix see the same operands as before.  Wider
+    // E keeps the selects (E more live doubles would spill).
+    constexpr bool QM = E <= 16;
+    double qm[QM ? E : 1];
+#pragma unroll
+    for (int i = 0; i < (QM ? E : 1); ++i) qm[i] = (c0 + i < n) ? q : 0.0;
     double p[E];                         // P[row][c0 + i]
     double p0 = 1.0;                     // P[row][0] = a^row (k-major only: lane 0's left neighbour)
 #pragma unroll
@@ -94,8 +102,8 @@ __device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, cons
 #pragma unroll
             for (int i = 0; i < E; i += 2) {
                 double2 w;
-                w.x = (c0 + i < n) ? v[i] : 0.0;
-                w.y = (c0 + i + 1 < n) ? v[i + 1] : 0.0;
+                w.x = (QM || c0 + i < n) ? v[i] : 0.0;
+                w.y = (QM || c0 + i + 1 < n) ? v[i + 1] : 0.0;
                 if (j0 + i < ld CAFE_EXPERIMENT_K1_STORE_IF) row[(j0 + i) >> 1] = w;
             }
             return;
@@ -103,8 +111,8 @@ __device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, cons
 #pragma unroll
         for (int i = 0; i < E; i += 2) {
             double2 w;
-            w.x = (c0 + i < n) ? v[i] : 0.0;
-            w.y = (c0 + i + 1 < n) ? v[i + 1] : 0.0;
+            w.x = (QM || c0 + i < n) ? v[i] : 0.0;
+            w.y = (QM || c0 + i + 1 < n) ? v[i + 1] : 0.0;
             rowbuf[(j0 + i) >> 1] = w;
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): every lane's part of the row is in LDS
@@ -134,7 +142,7 @@ __device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, cons
         if (KMAJOR) {
             bool any = false;
 #pragma unroll
-            for (int i = 0; i < E; ++i) any = any || (c0 + i < n && v[i] != 0.0);
+            for (int i = 0; i < E; ++i) any = any || ((QM || c0 + i < n) && v[i] != 0.0);
             if (any) { first_nz = first_nz < r ? first_nz : r; last_nz = r; }
         } else {
 #pragma unroll
@@ -173,7 +181,7 @@ __device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, cons
     if (KMAJOR) {
         double v[E];                     // Pt[0][j] = P[j+1][0] = a^(j+1)
 #pragma unroll
-        for (int i = 0; i < E; ++i) v[i] = pow(a, (double)(c0 + i));
+        for (int i = 0; i < E; ++i) v[i] = (!QM || c0 + i < n) ? pow(a, (double)(c0 + i)) : 0.0;
         store_row(0, v);
         note(0, v);
     } else {
@@ -203,7 +211,7 @@ __device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, cons
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             double hh = fma(apow[i], carry, h[i]);
-            double v = fma(a, p[i], q * hh);
+            double v = fma(a, p[i], (QM ? qm[i] : q) * hh);
             v = v < 1.0 ? v : 1.0;
             p[i] = v > 0.0 ? v : 0.0;
         }
