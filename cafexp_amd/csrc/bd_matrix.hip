@@ -42,6 +42,17 @@
 
 namespace cafe {
 
+// 1 / r for the k-major scaling P[s][c] = (s/c) P[c][s]: the division (v_rcp_f64 + two scales + four FMAs + fix-up) sat in
+// every row step; the correctly rounded quotient is the same number whoever divides, so it is folded at compile time and read
+// with a scalar load (r is uniform).  Orders go up to bd_matrix_max_order() = 2048.
+struct InvTable {
+    double v[2048];
+    constexpr InvTable() : v() {
+        for (int i = 1; i < 2048; ++i) v[i] = 1.0 / (double)i;
+    }
+};
+__constant__ InvTable kInvR = InvTable();
+
 // DPP move of a double (two 32-bit halves); lanes without a source read 0
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ double dpp_move(double v) {
@@ -217,7 +228,7 @@ __device__ __forceinline__ void bd_matrix_build_one(const MatrixPool& pool, cons
         }
         p0 *= a;
         if (KMAJOR) {
-            const double inv_r = 1.0 / (double)r;
+            const double inv_r = kInvR.v[r];               // = 1.0 / (double)r, bit for bit
             double v[E];
 #pragma unroll
             for (int i = 0; i < E; ++i) {
